@@ -1,0 +1,112 @@
+/*
+ * rt_math_portable.h -- sinf/cosf/logf replacements whose result bits do not
+ * depend on the machine, the compiler or a math library.
+ *
+ * The render loop calls cosf/sinf on 2*pi*u and logf on u, u a multiple of
+ * 2^-23 in [0,1) (reference: src/math.c:230-231, src/main.c:555-556,696-697).
+ * A GPU has no libm; its native sin/cos/log instructions are approximate and
+ * differ from any CPU's.  These versions use only IEEE double add, multiply,
+ * fused multiply-add, one division, rint and conversions, every one written
+ * out explicitly (no a*b+c left for a compiler to fuse or not), so a host C
+ * build and a gfx950 device build produce identical floats.  The error before
+ * the final rounding to float is below 2^-45 relative, so the result is the
+ * correctly rounded float except when the exact value lies within 2^-21 ulp
+ * of a rounding boundary.
+ *
+ * Usable from C, C++ and HIP device code.
+ */
+#ifndef RT_MATH_PORTABLE_H
+#define RT_MATH_PORTABLE_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RT_MATH_FN __host__ __device__ static inline
+#else
+#define RT_MATH_FN static inline
+#endif
+
+/* sine and cosine of a float argument (radians), |x| <= 2^20; NaN beyond.
+ * Cody-Waite reduction to |y| <= pi/4 with a 33-bit + 53-bit split of pi/2
+ * (n * hi is exact), then Taylor polynomials through y^15 / y^16. */
+RT_MATH_FN void rt_sincosf(float x, float *sin_out, float *cos_out)
+{
+    const double xd = (double)x;
+    if (!(__builtin_fabs(xd) <= 1048576.0)) {
+        const float bad = x - x;   /* NaN for inf/NaN; large finite values are outside the contract */
+        *sin_out = bad + __builtin_nanf("");
+        *cos_out = bad + __builtin_nanf("");
+        return;
+    }
+    const double fn = __builtin_rint(xd * 6.36619772367581382433e-01);       /* x * 2/pi */
+    double y = __builtin_fma(-fn, 1.57079632673412561417e+00, xd);          /* pi/2, high 33 bits */
+    y = __builtin_fma(-fn, 6.07710050650619224932e-11, y);                   /* pi/2, the rest */
+    const int q = (int)fn & 3;
+    const double y2 = y * y;
+
+    double ps = 1.0 / 1307674368000.0;                                       /* 1/15! */
+    ps = __builtin_fma(ps, y2, -1.0 / 6227020800.0);                         /* 1/13! */
+    ps = __builtin_fma(ps, y2, 1.0 / 39916800.0);
+    ps = __builtin_fma(ps, y2, -1.0 / 362880.0);
+    ps = __builtin_fma(ps, y2, 1.0 / 5040.0);
+    ps = __builtin_fma(ps, y2, -1.0 / 120.0);
+    ps = __builtin_fma(ps, y2, 1.0 / 6.0);
+    const double y3 = y * y2;
+    const double sv = __builtin_fma(-y3, ps, y);                             /* y - y^3 (1/6 - ...) */
+
+    double pc = 1.0 / 20922789888000.0;                                      /* 1/16! */
+    pc = __builtin_fma(pc, y2, -1.0 / 87178291200.0);                        /* 1/14! */
+    pc = __builtin_fma(pc, y2, 1.0 / 479001600.0);
+    pc = __builtin_fma(pc, y2, -1.0 / 3628800.0);
+    pc = __builtin_fma(pc, y2, 1.0 / 40320.0);
+    pc = __builtin_fma(pc, y2, -1.0 / 720.0);
+    pc = __builtin_fma(pc, y2, 1.0 / 24.0);
+    pc = __builtin_fma(pc, y2, -0.5);
+    const double cv = __builtin_fma(y2, pc, 1.0);
+
+    const double s = (q & 1) ? cv : sv;
+    const double c = (q & 1) ? sv : cv;
+    *sin_out = (float)((q & 2) ? -s : s);
+    *cos_out = (float)(((q + 1) & 2) ? -c : c);
+}
+
+/* natural logarithm of a float; log(0) = -inf, log(x<0) = NaN, as libm.
+ * x = m * 2^e with m in (sqrt(1/2), sqrt(2)], log m = 2 atanh((m-1)/(m+1)). */
+RT_MATH_FN float rt_logf(float x)
+{
+    if (!(x > 0.0f)) {
+        if (x == 0.0f) return -__builtin_inff();
+        return (x - x) + __builtin_nanf("");
+    }
+    if (x == __builtin_inff()) return x;
+    const double xd = (double)x;             /* every finite float is a normal double */
+    uint64_t bits;
+    __builtin_memcpy(&bits, &xd, 8);
+    int e = (int)(bits >> 52) - 1023;
+    bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m;
+    __builtin_memcpy(&m, &bits, 8);
+    if (m > 1.41421356237309514547) { m = m * 0.5; e = e + 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 23.0;
+    p = __builtin_fma(p, s2, 1.0 / 21.0);
+    p = __builtin_fma(p, s2, 1.0 / 19.0);
+    p = __builtin_fma(p, s2, 1.0 / 17.0);
+    p = __builtin_fma(p, s2, 1.0 / 15.0);
+    p = __builtin_fma(p, s2, 1.0 / 13.0);
+    p = __builtin_fma(p, s2, 1.0 / 11.0);
+    p = __builtin_fma(p, s2, 1.0 / 9.0);
+    p = __builtin_fma(p, s2, 1.0 / 7.0);
+    p = __builtin_fma(p, s2, 1.0 / 5.0);
+    p = __builtin_fma(p, s2, 1.0 / 3.0);
+    const double s3 = s * s2;
+    const double atanh_s = __builtin_fma(s3, p, s);
+    const double two_atanh = atanh_s + atanh_s;
+    /* ln 2 split so that e * hi is exact (hi has 32 significant bits) */
+    double r = __builtin_fma((double)e, 1.90821492927058770002e-10, two_atanh);
+    r = __builtin_fma((double)e, 6.93147180369123816490e-01, r);
+    return (float)r;
+}
+
+#endif /* RT_MATH_PORTABLE_H */
