@@ -1,0 +1,157 @@
+/*
+ * rt_gpu.h -- C ABI of the MI355X render loop (librt_gpu.so).
+ *
+ * The library replaces ONE function of the host program, the per-pixel
+ * path-tracing loop
+ *
+ *     void raytrace_region(Job *job);            (reference: src/main.c:742)
+ *
+ * together with everything it calls (raytrace_ray src/main.c:611, find_ray_hit
+ * src/main.c:264, compute_light_contribution src/main.c:546, sample_texture
+ * src/math.c:269, the Random_Serie generator src/math.c:158-235) and the tile
+ * loop that feeds it (thread_entry_point src/main.c:804-833).  Scene loading,
+ * the scene records and image output stay with the host program.
+ *
+ * Plain C: pointers and sizes only.  All entry points return 0 on success and
+ * a negative rt_gpu_status otherwise; rt_gpu_last_error() gives the text.
+ * A scene handle may be used by one host thread at a time.
+ */
+#ifndef RT_GPU_H
+#define RT_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef RT_SCENE_TYPES_FROM_HOST
+/* Compiled inside the host program: reuse its own records (same layout). */
+typedef Scene      rt_scene;
+typedef Image3f    rt_image3f;
+typedef Rect2i     rt_rect2u;
+typedef Job        rt_job;
+typedef Ray        rt_ray;
+typedef Ray_Result rt_ray_result;
+#else
+#include "rt_scene.h"
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_gpu_status {
+    RT_GPU_OK = 0,
+    RT_GPU_ERR_ARGUMENT = -1,      /* NULL / out-of-range argument */
+    RT_GPU_ERR_SCENE = -2,         /* scene graph inconsistent (bad index, bad pointer, tree too deep) */
+    RT_GPU_ERR_DEVICE = -3,        /* a HIP call failed */
+    RT_GPU_ERR_NO_DEVICE = -4,     /* no usable GPU */
+    RT_GPU_ERR_MEMORY = -5         /* host or device allocation failed */
+} rt_gpu_status;
+
+typedef struct rt_gpu_scene rt_gpu_scene;      /* opaque: the scene flattened and resident in HBM */
+
+enum {
+    RT_GPU_FLAG_DETAILED_STATS = 1u << 0,  /* count node pops, triangle tests, ... (slower) */
+    RT_GPU_FLAG_ACCUMULATE     = 1u << 1,  /* pixels hold running UN-normalised sums: read, add, store */
+    RT_GPU_FLAG_COMPACT_BANDS  = 1u << 2   /* device output holds only this rank's bands, packed */
+};
+
+/* Optional knobs; pass NULL for the host program's behaviour.  Zero-fill, then
+ * set struct_size = sizeof(rt_gpu_options). */
+typedef struct rt_gpu_options {
+    uint32_t struct_size;
+    uint32_t max_segments;   /* path length cap; 0 = 64 (reference: src/main.c:624) */
+    uint32_t sample_offset;  /* index of the first sample of this call (sample batches) */
+    uint32_t spp_total;      /* sample count the final normalisation divides by; 0 = spp */
+    uint32_t flags;          /* RT_GPU_FLAG_* */
+    uint32_t band_rows;      /* split over devices: rows per band (multiple of 8); 0 = no split */
+    uint32_t band_rank;      /* this device renders bands rank, rank + count, ... of the region */
+    uint32_t band_count;
+} rt_gpu_options;
+
+/* Work counters of the calls since the last rt_gpu_reset_stats.  A "ray" is
+ * one closest-hit query (camera, bounce and shadow rays alike). */
+typedef struct rt_gpu_stats {
+    uint64_t samples, rays, shadow_rays;
+    uint64_t root_tests, interior_pops, leaf_pops, tri_tests, tri_hits, tex_lookups, rng_draws;
+                             /* the second line only with RT_GPU_FLAG_DETAILED_STATS */
+    double   kernel_ms;      /* device time of the render kernels (HIP events) */
+    uint32_t launches;
+    uint32_t reserved;
+} rt_gpu_stats;
+
+/* Library / device ------------------------------------------------------- */
+
+/* Number of usable GPUs (0 if none); never fails. */
+int rt_gpu_device_count(void);
+
+/* Text of the calling thread's last error ("" if none). */
+const char *rt_gpu_last_error(void);
+
+/* Scene ------------------------------------------------------------------
+ * Walks the host scene graph once (Scene, src/main.h:7-25: materials, spheres,
+ * planes, lights, mesh instances with their Mesh and box tree, textures),
+ * de-duplicates meshes and textures by pointer, flattens the box trees and
+ * uploads everything to the CURRENT HIP device.  No host pointer is kept
+ * after it returns.  What raytrace_region reads through job->scene on every
+ * call is read here once. */
+int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out);
+void rt_gpu_scene_destroy(rt_gpu_scene *scene);
+
+/* Replace the camera of a resident scene (Scene.camera, src/main.h:9). */
+int rt_gpu_scene_set_camera(rt_gpu_scene *scene, const void *camera /* Camera, 40 bytes */);
+
+/* Render ------------------------------------------------------------------
+ * Drop-in for raytrace_region (src/main.c:742) plus the tile loop around it
+ * (src/main.c:804-833): renders `spp` samples for every pixel of `region`
+ * and stores image->pixels[width*y + x] (host memory) exactly as the
+ * reference does.  Sample i of pixel p draws its random numbers from a
+ * counter-based stream keyed (seed, p, sample_offset + i), so the result does
+ * not depend on how the frame is cut into regions, bands or devices. */
+int rt_gpu_render_region(rt_gpu_scene *scene, rt_image3f *image, rt_rect2u region,
+                         uint32_t spp, uint64_t seed, const rt_gpu_options *options);
+
+/* The same render into DEVICE memory (width*height float RGB triples, or the
+ * packed bands of this rank with RT_GPU_FLAG_COMPACT_BANDS), asynchronous on
+ * `hip_stream` (a hipStream_t; NULL = the default stream).  The buffer belongs
+ * to the caller (e.g. a tensor that a collective will gather). */
+int rt_gpu_render_region_device(rt_gpu_scene *scene, float *device_pixels, uint32_t width, uint32_t height,
+                                rt_rect2u region, uint32_t spp, uint64_t seed,
+                                const rt_gpu_options *options, void *hip_stream);
+
+/* Multiply un-normalised sums (RT_GPU_FLAG_ACCUMULATE) by the reference's
+ * final factor 1/(0.5*0.5*2*pi*spp_total) (src/main.c:788). */
+int rt_gpu_normalize_device(float *device_pixels, size_t pixel_count, uint32_t spp_total, void *hip_stream);
+
+/* Bit-compatible replay of raytrace_region(Job*) for a batch of jobs, each
+ * with its own region, sample count and Random_Serie (Job, src/main.h:65-72):
+ * one GPU lane walks one job in the reference's order and consumes the job's
+ * AES generator stream exactly as the reference does.  jobs[i].scene is
+ * ignored (the resident scene is used); all jobs must share one image.
+ * Meant for validation and for small tiles; the counter-based entry points
+ * above are the fast path. */
+int rt_gpu_render_jobs(rt_gpu_scene *scene, const rt_job *jobs, uint32_t job_count,
+                       const rt_gpu_options *options);
+
+/* Batched find_ray_hit (src/main.c:264): out[i] = closest hit of rays[i] within
+ * max_distance, every field as the reference fills it. */
+int rt_gpu_find_ray_hit(rt_gpu_scene *scene, const rt_ray *rays, uint32_t ray_count,
+                        float max_distance, rt_ray_result *out);
+
+/* Gamma + truncating 8-bit quantiser of save_image (src/main.c:73-82) on host
+ * float pixels; rgb receives 3 bytes per pixel. */
+int rt_gpu_quantize(const float *pixels, size_t pixel_count, uint8_t *rgb);
+
+/* Statistics ---------------------------------------------------------------- */
+int rt_gpu_get_stats(rt_gpu_scene *scene, rt_gpu_stats *out);
+int rt_gpu_reset_stats(rt_gpu_scene *scene);
+
+/* Self-test hook: evaluates the device's sin/cos/log/divide/sqrt building
+ * blocks on n host floats (x, and y for the quotient x/y) so that a test can
+ * compare them bit for bit with the host's.  Any output pointer may be NULL. */
+int rt_gpu_eval_math(const float *x, const float *y, size_t n,
+                     float *sin_out, float *cos_out, float *log_out, float *div_out, float *sqrt_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_GPU_H */

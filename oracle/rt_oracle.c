@@ -484,10 +484,10 @@ static void orc_direct_light(orc_ctx *cx, const rt_scene *scene, const rt_ray_re
 static v3 orc_texel(const rt_image3f *tex, rt_vec2f uv, orc_stats *st)
 {
     if (st) st->tex_lookups++;
-    int ui = (int)(uv.x * (tex->size.x - 0.5));
-    int vi = (int)(uv.y * (tex->size.y - 0.5));
-    if (ui < 0) ui = 0; if (ui >= (int)tex->size.x) ui = (int)tex->size.x - 1;
-    if (vi < 0) vi = 0; if (vi >= (int)tex->size.y) vi = (int)tex->size.y - 1;
+    double fu = uv.x * (tex->size.x - 0.5);
+    double fv = uv.y * (tex->size.y - 0.5);
+    int ui = !(fu >= 0.0) ? 0 : (fu >= (double)tex->size.x ? (int)tex->size.x - 1 : (int)fu);
+    int vi = !(fv >= 0.0) ? 0 : (fv >= (double)tex->size.y ? (int)tex->size.y - 1 : (int)fv);
     return tex->pixels[(size_t)vi * tex->size.x + ui];
 }
 

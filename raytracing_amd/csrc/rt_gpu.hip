@@ -1,0 +1,696 @@
+/*
+ * rt_gpu.hip -- kernels and C ABI of librt_gpu.so (gfx950 only).
+ *
+ * Entry points are declared, with the reference function each one replaces,
+ * in include/rt_gpu.h.  Device code lives in rt_trace.hpp; the host scene
+ * graph is flattened by rt_flatten.cpp.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_gpu.h"
+#include "rt_flatten.h"
+#include "rt_trace.hpp"
+
+#define RT_BLOCK 256                 /* 4 waves; a wave owns an 8x8 pixel block */
+#define RT_STAT_WORDS 10
+
+/* ------------------------------------------------------------------------ */
+/* kernels                                                                   */
+/* ------------------------------------------------------------------------ */
+
+struct RenderParams {
+    rt_dev_scene S;
+    float   *pixels;
+    uint64_t *stats;
+    uint32_t width, height;          /* image */
+    uint32_t x0, y0, w, h;           /* region */
+    uint32_t blocks_x, block_rows;   /* 8x8 pixel blocks this launch walks */
+    uint32_t band_blocks, band_rank, band_count;   /* 0 band_blocks = no split */
+    uint32_t out_pitch;              /* pixels per output row */
+    uint32_t compact;                /* output rows are this rank's rows, packed */
+    uint32_t spp, sample_offset, seed0, seed1;
+    int      max_segments;
+    uint32_t accumulate;
+    float    norm, half_w, half_h;
+};
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <bool STATS>
+__device__ __forceinline__ void flush_counters(const rt::Counters &cn, uint64_t *stats)
+{
+    if (!stats) return;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&cn);
+    const int lane = threadIdx.x & 63;
+    if (STATS) {
+#pragma unroll
+        for (int k = 0; k < RT_STAT_WORDS; k++) {
+            uint32_t s = wave_sum(w[k]);
+            if (lane == 0 && s) atomicAdd(reinterpret_cast<unsigned long long *>(stats + k), (unsigned long long)s);
+        }
+    } else {
+        uint32_t s = wave_sum(cn.rays);
+        if (lane == 0 && s) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 1), (unsigned long long)s);
+    }
+}
+
+/* One lane = one pixel, all of its samples in order (the running sum of a pixel
+ * is a sequential float sum, src/main.c:785).  One wave = one 8x8 pixel block. */
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK)
+rt_render_pixels_kernel(const RenderParams P)
+{
+    extern __shared__ uint32_t lds[];
+    rt::Stack stk; stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK;
+    rt::Counters cn; memset(&cn, 0, sizeof(cn));
+
+    const uint32_t wave = (blockIdx.x * RT_BLOCK + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    bool active = wave < P.blocks_x * P.block_rows;
+    uint32_t bx = 0, by = 0, own_row = 0;
+    if (active) {
+        bx = wave % P.blocks_x;
+        own_row = wave / P.blocks_x;
+        by = own_row;
+        if (P.band_blocks) {
+            uint32_t k = own_row / P.band_blocks, in = own_row % P.band_blocks;
+            by = (k * P.band_count + P.band_rank) * P.band_blocks + in;
+        }
+    }
+    const uint32_t lx = bx * 8 + (lane & 7), ly = by * 8 + (lane >> 3);
+    active = active && lx < P.w && ly < P.h;
+    if (active) {
+        const uint32_t x = P.x0 + lx, y = P.y0 + ly;
+        const uint32_t pixel = P.width * y + x;
+        size_t out = P.compact ? ((size_t)(own_row * 8 + (lane >> 3)) * P.out_pitch + lx)
+                               : ((size_t)y * P.out_pitch + x);
+        float *dst = P.pixels + 3 * out;
+        rt::f3 total = rt::mk(0, 0, 0);
+        if (P.accumulate) total = rt::mk(dst[0], dst[1], dst[2]);
+        rt::CounterRng rng;
+        for (uint32_t i = 0; i < P.spp; i++) {
+            rng.begin(P.seed0, P.seed1, pixel, P.sample_offset + i);
+            rt::f3 c = rt::sample_pixel<rt::CounterRng, STATS>(P.S, rng, stk, x, y, P.half_w, P.half_h,
+                                                                 P.max_segments, cn);
+            total = rt::add(total, c);
+        }
+        if (!P.accumulate) total = rt::scale(total, P.norm);
+        dst[0] = total.x; dst[1] = total.y; dst[2] = total.z;
+    }
+    flush_counters<STATS>(cn, P.stats);
+}
+
+/* ---- replay of host jobs: one lane = one Job (src/main.h:65-72), walked in the
+ * host's order with the job's own AES generator state ---------------------- */
+struct DevJob { uint32_t x0, y0, w, h, spp; float norm; uint32_t serie[8]; };
+
+struct JobParams {
+    rt_dev_scene S;
+    float *pixels; uint64_t *stats;
+    const DevJob *jobs; const uint32_t *aes_table;
+    uint32_t job_count, width, height;
+    int max_segments;
+    float half_w, half_h;
+};
+
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK)
+rt_render_jobs_kernel(const JobParams P)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t *td = lds;                         /* 256 words, then the stacks */
+    for (int i = threadIdx.x; i < 256; i += RT_BLOCK) td[i] = P.aes_table[i];
+    __syncthreads();
+    rt::Stack stk; stk.base = lds + 256 + threadIdx.x; stk.stride = RT_BLOCK;
+    rt::Counters cn; memset(&cn, 0, sizeof(cn));
+
+    const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (j < P.job_count) {
+        const DevJob job = P.jobs[j];
+        rt::AesRng rng; rng.td = td;
+        for (int k = 0; k < 4; k++) { rng.a[k] = job.serie[k]; rng.b[k] = job.serie[4 + k]; }
+        const float norm = job.norm;
+        for (uint32_t y = job.y0; y < job.y0 + job.h; y++)
+            for (uint32_t x = job.x0; x < job.x0 + job.w; x++) {
+                rt::f3 total = rt::mk(0, 0, 0);
+                for (uint32_t i = 0; i < job.spp; i++) {
+                    rt::f3 c = rt::sample_pixel<rt::AesRng, STATS>(P.S, rng, stk, x, y, P.half_w, P.half_h,
+                                                                     P.max_segments, cn);
+                    total = rt::add(total, c);
+                }
+                total = rt::scale(total, norm);
+                float *dst = P.pixels + 3 * ((size_t)P.width * y + x);
+                dst[0] = total.x; dst[1] = total.y; dst[2] = total.z;
+            }
+    }
+    flush_counters<STATS>(cn, P.stats);
+}
+
+/* ---- batched closest-hit probe, output in the host's Ray_Result layout ----- */
+struct HitParams {
+    rt_dev_scene S;
+    const float *rays;          /* 6 floats per ray */
+    uint8_t *results;           /* 72 bytes per ray */
+    uint64_t *stats;
+    uint32_t count;
+    float max_distance;
+};
+
+__global__ void __launch_bounds__(RT_BLOCK)
+rt_find_hit_kernel(const HitParams P)
+{
+    extern __shared__ uint32_t lds[];
+    rt::Stack stk; stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK;
+    rt::Counters cn; memset(&cn, 0, sizeof(cn));
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i < P.count) {
+        rt::f3 o = rt::ld3(P.rays + 6 * i), d = rt::ld3(P.rays + 6 * i + 3);
+        rt::Hit h;
+        rt::closest_hit<false, true>(P.S, o, d, P.max_distance, stk, h, cn);
+        rt::Surface sf;
+        rt::surface_of<true>(P.S, o, d, h, sf, cn);
+        uint32_t *w = reinterpret_cast<uint32_t *>(P.results + 72 * (size_t)i);
+        float *f = reinterpret_cast<float *>(w);
+        const bool hit = h.type != rt::HIT_NONE;
+        w[0] = hit ? 1u : 0u;
+        w[1] = hit ? (uint32_t)h.type : 0u;
+        w[2] = h.id;
+        w[3] = h.type == rt::HIT_TRIANGLE ? h.inst : 0u;
+        f[4] = sf.p.x; f[5] = sf.p.y; f[6] = sf.p.z;
+        f[7] = sf.n.x; f[8] = sf.n.y; f[9] = sf.n.z;
+        f[10] = h.t; f[11] = sf.alpha; f[12] = h.beta; f[13] = h.gamma;
+        f[14] = sf.u; f[15] = sf.v;
+        w[16] = h.entered ? 1u : 0u;
+        w[17] = (uint32_t)h.material;
+    }
+    flush_counters<true>(cn, P.stats);
+}
+
+__global__ void rt_normalize_kernel(float *p, size_t n, float factor)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = p[i] * factor;
+}
+
+__global__ void rt_math_kernel(const float *x, const float *y, size_t n, float *s, float *c, float *l,
+                               float *q, float *r)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float sn, cs;
+    rt_sincosf(x[i], &sn, &cs);
+    if (s) s[i] = sn;
+    if (c) c[i] = cs;
+    if (l) l[i] = rt_logf(x[i]);
+    if (q && y) q[i] = x[i] / y[i];
+    if (r) r[i] = __builtin_sqrtf(x[i]);
+}
+
+/* ------------------------------------------------------------------------ */
+/* host side                                                                 */
+/* ------------------------------------------------------------------------ */
+
+static thread_local std::string g_error;
+
+static int fail(int code, const std::string &what)
+{
+    g_error = what;
+    return code;
+}
+
+#define RT_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(RT_GPU_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct rt_gpu_scene {
+    int device = 0;
+    rt_dev_scene dev;
+    float field_of_view = 0.0f;
+    std::vector<void *> allocations;
+    uint64_t *d_stats = nullptr;
+    uint32_t *d_aes_table = nullptr;
+    float *d_frame = nullptr; size_t frame_floats = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timers;   /* pending kernel timings */
+    std::vector<hipEvent_t> spare_events;
+    double kernel_ms = 0.0;
+    uint32_t launches = 0;
+    uint64_t samples = 0;
+};
+
+template <class T>
+static int upload(rt_gpu_scene *s, const std::vector<T> &host, const T **dev)
+{
+    *dev = nullptr;
+    size_t bytes = sizeof(T) * (host.empty() ? 1 : host.size());
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed while uploading the scene");
+    s->allocations.push_back(p);
+    if (!host.empty()) RT_HIP(hipMemcpy(p, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice));
+    *dev = static_cast<const T *>(p);
+    return 0;
+}
+
+/* combined InvSubBytes + InvMixColumns column table of the AES decryption
+ * round (FIPS-197 5.3): word x = {14,9,13,11} . Sinv[x], lowest byte = row 0 */
+static void build_aes_table(uint32_t table[256])
+{
+    auto xt = [](uint8_t a) { return (uint8_t)((a << 1) ^ ((a & 0x80) ? 0x1b : 0)); };
+    auto mulg = [&](uint8_t a, uint8_t b) {
+        uint8_t p = 0;
+        while (b) { if (b & 1) p ^= a; a = xt(a); b >>= 1; }
+        return p;
+    };
+    uint8_t sbox[256], inv[256];
+    for (int x = 0; x < 256; x++) {
+        uint8_t i = 0;
+        if (x) for (int y = 1; y < 256; y++) if (mulg((uint8_t)x, (uint8_t)y) == 1) { i = (uint8_t)y; break; }
+        uint8_t s = i, r = i;
+        for (int k = 0; k < 4; k++) { r = (uint8_t)((r << 1) | (r >> 7)); s ^= r; }
+        sbox[x] = s ^ 0x63;
+    }
+    for (int x = 0; x < 256; x++) inv[sbox[x]] = (uint8_t)x;
+    for (int x = 0; x < 256; x++) {
+        uint8_t s = inv[x];
+        table[x] = (uint32_t)mulg(s, 14) | ((uint32_t)mulg(s, 9) << 8) | ((uint32_t)mulg(s, 13) << 16) |
+                   ((uint32_t)mulg(s, 11) << 24);
+    }
+}
+
+extern "C" {
+
+int rt_gpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *rt_gpu_last_error(void) { return g_error.c_str(); }
+
+void rt_gpu_scene_destroy(rt_gpu_scene *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    for (void *p : s->allocations) (void)hipFree(p);
+    if (s->d_frame) (void)hipFree(s->d_frame);
+    for (auto &t : s->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
+    for (auto e : s->spare_events) (void)hipEventDestroy(e);
+    delete s;
+}
+
+int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
+{
+    if (!scene || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_scene_create: NULL argument");
+    *out = nullptr;
+    if (rt_gpu_device_count() <= 0) return fail(RT_GPU_ERR_NO_DEVICE, "no HIP device is visible");
+    rt_flat_scene flat;
+    if (rt_flatten_scene(scene, flat) != 0) return fail(RT_GPU_ERR_SCENE, "scene rejected: " + flat.error);
+
+    rt_gpu_scene *s = new rt_gpu_scene();
+    int rc = 0;
+    do {
+        if (hipGetDevice(&s->device) != hipSuccess) { rc = fail(RT_GPU_ERR_DEVICE, "hipGetDevice failed"); break; }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) { rc = fail(RT_GPU_ERR_DEVICE, "hipGetDeviceProperties failed"); break; }
+        size_t lds_need = (size_t)RT_BLOCK * flat.stack_cap * 4 + 1024;
+        if (lds_need > prop.sharedMemPerBlock) {
+            rc = fail(RT_GPU_ERR_SCENE, "box tree too deep for the LDS traversal stack (" + std::to_string(flat.stack_cap) + " levels)");
+            break;
+        }
+        memset(&s->dev, 0, sizeof(s->dev));
+        s->dev.cam = flat.camera;
+        s->field_of_view = flat.field_of_view;
+        s->dev.light_count = (int32_t)flat.lights.size();
+        s->dev.sphere_count = (int32_t)flat.spheres.size();
+        s->dev.plane_count = (int32_t)flat.planes.size();
+        s->dev.instance_count = (int32_t)flat.instances.size();
+        s->dev.material_count = (int32_t)flat.materials.size();
+        s->dev.texture_count = (int32_t)flat.textures.size();
+        s->dev.stack_cap = flat.stack_cap;
+        if ((rc = upload(s, flat.lights, &s->dev.lights))) break;
+        if ((rc = upload(s, flat.spheres, &s->dev.spheres))) break;
+        if ((rc = upload(s, flat.planes, &s->dev.planes))) break;
+        if ((rc = upload(s, flat.instances, &s->dev.instances))) break;
+        if ((rc = upload(s, flat.meshes, &s->dev.meshes))) break;
+        if ((rc = upload(s, flat.materials, &s->dev.materials))) break;
+        if ((rc = upload(s, flat.textures, &s->dev.textures))) break;
+        if ((rc = upload(s, flat.nodes, &s->dev.nodes))) break;
+        if ((rc = upload(s, flat.tris, &s->dev.tris))) break;
+        if ((rc = upload(s, flat.attrs, &s->dev.attrs))) break;
+        if ((rc = upload(s, flat.texels, &s->dev.texels))) break;
+        std::vector<uint64_t> zeros(RT_STAT_WORDS, 0);
+        const uint64_t *st = nullptr;
+        if ((rc = upload(s, zeros, &st))) break;
+        s->d_stats = const_cast<uint64_t *>(st);
+        std::vector<uint32_t> table(256);
+        build_aes_table(table.data());
+        const uint32_t *tb = nullptr;
+        if ((rc = upload(s, table, &tb))) break;
+        s->d_aes_table = const_cast<uint32_t *>(tb);
+    } while (0);
+    if (rc) { rt_gpu_scene_destroy(s); return rc; }
+    *out = s;
+    return RT_GPU_OK;
+}
+
+int rt_gpu_scene_set_camera(rt_gpu_scene *s, const void *camera)
+{
+    if (!s || !camera) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_scene_set_camera: NULL argument");
+    const rt_camera *c = static_cast<const rt_camera *>(camera);
+    rt_flatten_camera(c, s->dev.cam);
+    s->field_of_view = c->field_of_view;
+    return RT_GPU_OK;
+}
+
+static hipEvent_t take_event(rt_gpu_scene *s)
+{
+    if (!s->spare_events.empty()) { hipEvent_t e = s->spare_events.back(); s->spare_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+static void settle_timers(rt_gpu_scene *s)
+{
+    for (auto &t : s->timers) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(t.second) == hipSuccess && hipEventElapsedTime(&ms, t.first, t.second) == hipSuccess)
+            s->kernel_ms += ms;
+        s->spare_events.push_back(t.first);
+        s->spare_events.push_back(t.second);
+    }
+    s->timers.clear();
+}
+
+/* which 8-row block rows of the region this launch walks; *own_rows = pixel rows among them */
+static int launch_geometry(const rt_gpu_options *o, rt_rect2u region, RenderParams &P, uint32_t *own_rows)
+{
+    uint32_t block_rows_total = (region.size.y + 7) / 8;
+    P.blocks_x = (region.size.x + 7) / 8;
+    P.band_blocks = 0; P.band_rank = 0; P.band_count = 1;
+    P.block_rows = block_rows_total;
+    if (o && o->band_rows) {
+        if (o->band_rows % 8 || !o->band_count || o->band_rank >= o->band_count)
+            return fail(RT_GPU_ERR_ARGUMENT, "band_rows must be a multiple of 8 and band_rank < band_count");
+        P.band_blocks = o->band_rows / 8; P.band_rank = o->band_rank; P.band_count = o->band_count;
+        uint32_t bands = (block_rows_total + P.band_blocks - 1) / P.band_blocks;
+        uint32_t own = 0, rows = 0;
+        for (uint32_t b = P.band_rank; b < bands; b += P.band_count) {
+            uint32_t left = block_rows_total - b * P.band_blocks;
+            own += left < P.band_blocks ? left : P.band_blocks;
+            uint32_t left_rows = region.size.y - b * o->band_rows;
+            rows += left_rows < o->band_rows ? left_rows : o->band_rows;
+        }
+        /* a short band can only be the last band of the region, hence the last one a rank owns:
+         * the kernel's packed numbering k*band_blocks+i stays valid */
+        P.block_rows = own;
+        *own_rows = rows;
+        return 0;
+    }
+    *own_rows = region.size.y;
+    return 0;
+}
+
+int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t width, uint32_t height,
+                                rt_rect2u region, uint32_t spp, uint64_t seed,
+                                const rt_gpu_options *o, void *hip_stream)
+{
+    if (!s || !device_pixels) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_render_region_device: NULL argument");
+    if (o && o->struct_size != sizeof(rt_gpu_options)) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_options.struct_size mismatch");
+    if (!width || !height || !region.size.x || !region.size.y || !spp) return fail(RT_GPU_ERR_ARGUMENT, "empty image, region or sample count");
+    if ((uint64_t)region.point.x + region.size.x > width || (uint64_t)region.point.y + region.size.y > height)
+        return fail(RT_GPU_ERR_ARGUMENT, "region exceeds the image");
+    if ((uint64_t)width * height > 0xFFFFFFFFull) return fail(RT_GPU_ERR_ARGUMENT, "image too large for 32-bit pixel indices");
+    RT_HIP(hipSetDevice(s->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+
+    RenderParams P;
+    memset(&P, 0, sizeof(P));
+    uint32_t own_rows = 0;
+    int rc = launch_geometry(o, region, P, &own_rows);
+    if (rc) return rc;
+    const uint32_t flags = o ? o->flags : 0;
+    P.S = s->dev;
+    P.S.cam.focal = rt_camera_focal(s->field_of_view, height);
+    P.pixels = device_pixels; P.stats = s->d_stats;
+    P.width = width; P.height = height;
+    P.x0 = region.point.x; P.y0 = region.point.y; P.w = region.size.x; P.h = region.size.y;
+    P.compact = (flags & RT_GPU_FLAG_COMPACT_BANDS) ? 1 : 0;
+    P.out_pitch = P.compact ? region.size.x : width;
+    P.spp = spp; P.sample_offset = o ? o->sample_offset : 0;
+    P.seed0 = (uint32_t)seed; P.seed1 = (uint32_t)(seed >> 32);
+    P.max_segments = (o && o->max_segments) ? (int)o->max_segments : 64;
+    P.accumulate = (flags & RT_GPU_FLAG_ACCUMULATE) ? 1 : 0;
+    P.norm = rt_pixel_norm((o && o->spp_total) ? o->spp_total : spp);
+    P.half_w = (float)width / 2.0f; P.half_h = (float)height / 2.0f;
+    if (P.block_rows == 0) return RT_GPU_OK;
+
+    const uint64_t waves = (uint64_t)P.blocks_x * P.block_rows;
+    const uint32_t grid = (uint32_t)((waves * 64 + RT_BLOCK - 1) / RT_BLOCK);
+    const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
+
+    hipEvent_t e0 = take_event(s), e1 = take_event(s);
+    if (e0 && e1) RT_HIP(hipEventRecord(e0, stream));
+    if (flags & RT_GPU_FLAG_DETAILED_STATS)
+        hipLaunchKernelGGL(rt_render_pixels_kernel<true>, dim3(grid), dim3(RT_BLOCK), lds, stream, P);
+    else
+        hipLaunchKernelGGL(rt_render_pixels_kernel<false>, dim3(grid), dim3(RT_BLOCK), lds, stream, P);
+    RT_HIP(hipGetLastError());
+    if (e0 && e1) { RT_HIP(hipEventRecord(e1, stream)); s->timers.emplace_back(e0, e1); }
+    if (s->timers.size() > 2048) settle_timers(s);
+    s->launches++;
+    s->samples += (uint64_t)spp * own_rows * region.size.x;
+    return RT_GPU_OK;
+}
+
+static int ensure_frame(rt_gpu_scene *s, size_t floats)
+{
+    if (s->frame_floats >= floats) return 0;
+    if (s->d_frame) { (void)hipFree(s->d_frame); s->d_frame = nullptr; s->frame_floats = 0; }
+    if (hipMalloc(reinterpret_cast<void **>(&s->d_frame), floats * sizeof(float)) != hipSuccess)
+        return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the frame buffer");
+    s->frame_floats = floats;
+    return 0;
+}
+
+int rt_gpu_render_region(rt_gpu_scene *s, rt_image3f *image, rt_rect2u region, uint32_t spp, uint64_t seed,
+                         const rt_gpu_options *o)
+{
+    if (!s || !image || !image->pixels) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_render_region: NULL argument");
+    if (o && (o->flags & RT_GPU_FLAG_COMPACT_BANDS)) return fail(RT_GPU_ERR_ARGUMENT, "compact bands are a device-buffer layout");
+    const uint32_t W = image->size.x, H = image->size.y;
+    if ((uint64_t)region.point.x + region.size.x > W || (uint64_t)region.point.y + region.size.y > H)
+        return fail(RT_GPU_ERR_ARGUMENT, "region exceeds the image");
+    if (!region.size.x || !region.size.y) return fail(RT_GPU_ERR_ARGUMENT, "empty region");
+    RT_HIP(hipSetDevice(s->device));
+    int rc = ensure_frame(s, (size_t)W * H * 3);
+    if (rc) return rc;
+    /* only the region's rows travel; pixels outside the region keep the host's values */
+    const size_t row_bytes = (size_t)region.size.x * 3 * sizeof(float);
+    float *d0 = s->d_frame + 3 * ((size_t)W * region.point.y + region.point.x);
+    float *h0 = &image->pixels[0].x + 3 * ((size_t)W * region.point.y + region.point.x);
+    const size_t pitch = (size_t)W * 3 * sizeof(float);
+    if (o && (o->flags & RT_GPU_FLAG_ACCUMULATE))
+        RT_HIP(hipMemcpy2D(d0, pitch, h0, pitch, row_bytes, region.size.y, hipMemcpyHostToDevice));
+    rc = rt_gpu_render_region_device(s, s->d_frame, W, H, region, spp, seed, o, nullptr);
+    if (rc) return rc;
+    RT_HIP(hipDeviceSynchronize());
+    if (o && o->band_rows) {
+        /* copy back only the rows of this rank's bands */
+        const uint32_t band = o->band_rows;
+        for (uint32_t b = o->band_rank; (uint64_t)b * band < region.size.y; b += o->band_count) {
+            uint32_t r0 = b * band, rows = region.size.y - r0 < band ? region.size.y - r0 : band;
+            RT_HIP(hipMemcpy2D(h0 + (size_t)r0 * W * 3, pitch, d0 + (size_t)r0 * W * 3, pitch, row_bytes, rows,
+                               hipMemcpyDeviceToHost));
+        }
+    } else {
+        RT_HIP(hipMemcpy2D(h0, pitch, d0, pitch, row_bytes, region.size.y, hipMemcpyDeviceToHost));
+    }
+    return RT_GPU_OK;
+}
+
+int rt_gpu_normalize_device(float *device_pixels, size_t pixel_count, uint32_t spp_total, void *hip_stream)
+{
+    if (!device_pixels || !spp_total) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_normalize_device: bad argument");
+    size_t n = pixel_count * 3;
+    if (!n) return RT_GPU_OK;
+    hipLaunchKernelGGL(rt_normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(hip_stream), device_pixels, n, rt_pixel_norm(spp_total));
+    RT_HIP(hipGetLastError());
+    return RT_GPU_OK;
+}
+
+int rt_gpu_render_jobs(rt_gpu_scene *s, const rt_job *jobs, uint32_t job_count, const rt_gpu_options *o)
+{
+    if (!s || !jobs) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_render_jobs: NULL argument");
+    if (!job_count) return RT_GPU_OK;
+    if (o && o->struct_size != sizeof(rt_gpu_options)) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_options.struct_size mismatch");
+    rt_image3f *image = jobs[0].image;
+    if (!image || !image->pixels) return fail(RT_GPU_ERR_ARGUMENT, "job without an image");
+    const uint32_t W = image->size.x, H = image->size.y;
+    std::vector<DevJob> dj(job_count);
+    for (uint32_t i = 0; i < job_count; i++) {
+        const rt_job &j = jobs[i];
+        if (j.image != image) return fail(RT_GPU_ERR_ARGUMENT, "all jobs of one call must share one image");
+        if ((uint64_t)j.region.point.x + j.region.size.x > W || (uint64_t)j.region.point.y + j.region.size.y > H)
+            return fail(RT_GPU_ERR_ARGUMENT, "job region exceeds the image");
+        if (!j.ray_per_pixel) return fail(RT_GPU_ERR_ARGUMENT, "job with zero samples per pixel");
+        dj[i].x0 = j.region.point.x; dj[i].y0 = j.region.point.y;
+        dj[i].w = j.region.size.x; dj[i].h = j.region.size.y; dj[i].spp = j.ray_per_pixel;
+        dj[i].norm = rt_pixel_norm(j.ray_per_pixel);
+        memcpy(dj[i].serie, j.serie.bytes, 32);
+    }
+    RT_HIP(hipSetDevice(s->device));
+    int rc = ensure_frame(s, (size_t)W * H * 3);
+    if (rc) return rc;
+    RT_HIP(hipMemcpy(s->d_frame, &image->pixels[0].x, (size_t)W * H * 12, hipMemcpyHostToDevice));
+    DevJob *d_jobs = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&d_jobs), sizeof(DevJob) * job_count) != hipSuccess)
+        return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the job table");
+    hipError_t e = hipMemcpy(d_jobs, dj.data(), sizeof(DevJob) * job_count, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d_jobs); return fail(RT_GPU_ERR_DEVICE, "job upload failed"); }
+
+    JobParams P;
+    memset(&P, 0, sizeof(P));
+    P.S = s->dev;
+    P.S.cam.focal = rt_camera_focal(s->field_of_view, H);
+    P.pixels = s->d_frame; P.stats = s->d_stats; P.jobs = d_jobs; P.aes_table = s->d_aes_table;
+    P.job_count = job_count; P.width = W; P.height = H;
+    P.max_segments = (o && o->max_segments) ? (int)o->max_segments : 64;
+    P.half_w = (float)W / 2.0f; P.half_h = (float)H / 2.0f;
+    const uint32_t grid = (job_count + RT_BLOCK - 1) / RT_BLOCK;
+    const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4 + 1024;
+    hipEvent_t e0 = take_event(s), e1 = take_event(s);
+    if (e0 && e1) (void)hipEventRecord(e0, nullptr);
+    if (o && (o->flags & RT_GPU_FLAG_DETAILED_STATS))
+        hipLaunchKernelGGL(rt_render_jobs_kernel<true>, dim3(grid), dim3(RT_BLOCK), lds, nullptr, P);
+    else
+        hipLaunchKernelGGL(rt_render_jobs_kernel<false>, dim3(grid), dim3(RT_BLOCK), lds, nullptr, P);
+    e = hipGetLastError();
+    if (e0 && e1) { (void)hipEventRecord(e1, nullptr); s->timers.emplace_back(e0, e1); }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d_jobs);
+    if (e != hipSuccess) return fail(RT_GPU_ERR_DEVICE, std::string("job kernel: ") + hipGetErrorString(e));
+    s->launches++;
+    RT_HIP(hipMemcpy(&image->pixels[0].x, s->d_frame, (size_t)W * H * 12, hipMemcpyDeviceToHost));
+    return RT_GPU_OK;
+}
+
+int rt_gpu_find_ray_hit(rt_gpu_scene *s, const rt_ray *rays, uint32_t ray_count, float max_distance,
+                        rt_ray_result *out)
+{
+    if (!s || !rays || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_find_ray_hit: NULL argument");
+    if (!ray_count) return RT_GPU_OK;
+    static_assert(sizeof(rt_ray) == 24 && sizeof(rt_ray_result) == 72, "host record layout");
+    RT_HIP(hipSetDevice(s->device));
+    float *d_rays = nullptr; uint8_t *d_res = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&d_rays), (size_t)ray_count * 24) != hipSuccess)
+        return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the ray table");
+    if (hipMalloc(reinterpret_cast<void **>(&d_res), (size_t)ray_count * 72) != hipSuccess) {
+        (void)hipFree(d_rays);
+        return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the result table");
+    }
+    hipError_t e = hipMemcpy(d_rays, rays, (size_t)ray_count * 24, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_res, 0, (size_t)ray_count * 72);
+    if (e == hipSuccess) {
+        HitParams P;
+        memset(&P, 0, sizeof(P));
+        P.S = s->dev; P.rays = d_rays; P.results = d_res; P.stats = s->d_stats;
+        P.count = ray_count; P.max_distance = max_distance;
+        hipLaunchKernelGGL(rt_find_hit_kernel, dim3((ray_count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK),
+                           (size_t)RT_BLOCK * s->dev.stack_cap * 4, nullptr, P);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d_res, (size_t)ray_count * 72, hipMemcpyDeviceToHost);
+    (void)hipFree(d_rays); (void)hipFree(d_res);
+    if (e != hipSuccess) return fail(RT_GPU_ERR_DEVICE, std::string("closest-hit probe: ") + hipGetErrorString(e));
+    return RT_GPU_OK;
+}
+
+/* src/main.c:73-82 on the host: min(c,1) (a NaN becomes 1), powf(c, 1/2.2f), *255, truncate */
+int rt_gpu_quantize(const float *pixels, size_t pixel_count, uint8_t *rgb)
+{
+    if (!pixels || !rgb) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_quantize: NULL argument");
+    for (size_t i = 0; i < 3 * pixel_count; i++) {
+        float c = pixels[i] < 1.0f ? pixels[i] : 1.0f;
+        c = powf(c, 1.0f / 2.2f);
+        c = c * 255.0f;
+        rgb[i] = (uint8_t)c;
+    }
+    return RT_GPU_OK;
+}
+
+int rt_gpu_get_stats(rt_gpu_scene *s, rt_gpu_stats *out)
+{
+    if (!s || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_get_stats: NULL argument");
+    RT_HIP(hipSetDevice(s->device));
+    RT_HIP(hipDeviceSynchronize());
+    settle_timers(s);
+    uint64_t w[RT_STAT_WORDS];
+    RT_HIP(hipMemcpy(w, s->d_stats, sizeof(w), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    out->samples = w[0] ? w[0] : s->samples;
+    out->rays = w[1]; out->shadow_rays = w[2]; out->root_tests = w[3]; out->interior_pops = w[4];
+    out->leaf_pops = w[5]; out->tri_tests = w[6]; out->tri_hits = w[7]; out->tex_lookups = w[8];
+    out->rng_draws = w[9];
+    out->kernel_ms = s->kernel_ms;
+    out->launches = s->launches;
+    return RT_GPU_OK;
+}
+
+int rt_gpu_reset_stats(rt_gpu_scene *s)
+{
+    if (!s) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_reset_stats: NULL argument");
+    RT_HIP(hipSetDevice(s->device));
+    RT_HIP(hipDeviceSynchronize());
+    settle_timers(s);
+    RT_HIP(hipMemset(s->d_stats, 0, sizeof(uint64_t) * RT_STAT_WORDS));
+    s->kernel_ms = 0.0; s->launches = 0; s->samples = 0;
+    return RT_GPU_OK;
+}
+
+int rt_gpu_eval_math(const float *x, const float *y, size_t n, float *sin_out, float *cos_out, float *log_out,
+                     float *div_out, float *sqrt_out)
+{
+    if (!x) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_eval_math: NULL argument");
+    if (!n) return RT_GPU_OK;
+    float *d[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const float *hin[2] = {x, y};
+    float *hout[5] = {sin_out, cos_out, log_out, div_out, sqrt_out};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 7 && e == hipSuccess; i++) {
+        bool wanted = i < 2 ? hin[i] != nullptr : hout[i - 2] != nullptr;
+        if (!wanted) continue;
+        e = hipMalloc(reinterpret_cast<void **>(&d[i]), n * sizeof(float));
+        if (e == hipSuccess && i < 2) e = hipMemcpy(d[i], hin[i], n * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rt_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr,
+                           d[0], d[1], n, d[2], d[3], d[4], d[5], d[6]);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    for (int i = 2; i < 7 && e == hipSuccess; i++)
+        if (d[i]) e = hipMemcpy(hout[i - 2], d[i], n * sizeof(float), hipMemcpyDeviceToHost);
+    for (int i = 0; i < 7; i++) if (d[i]) (void)hipFree(d[i]);
+    if (e != hipSuccess) return fail(RT_GPU_ERR_DEVICE, std::string("math probe: ") + hipGetErrorString(e));
+    return RT_GPU_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,174 @@
+"""ctypes binding of the C ABI in include/rt_gpu.h (librt_gpu.so).
+
+There is no fallback: if the HIP library is missing or no GPU is visible the
+calls raise.  Everything here is plumbing around the C entry points.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import scene_types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_gpu.so")
+
+FLAG_DETAILED_STATS = 1
+FLAG_ACCUMULATE = 2
+FLAG_COMPACT_BANDS = 4
+
+EXPORTS = [
+    "rt_gpu_device_count", "rt_gpu_last_error", "rt_gpu_scene_create", "rt_gpu_scene_destroy",
+    "rt_gpu_scene_set_camera", "rt_gpu_render_region", "rt_gpu_render_region_device",
+    "rt_gpu_normalize_device", "rt_gpu_render_jobs", "rt_gpu_find_ray_hit", "rt_gpu_quantize",
+    "rt_gpu_get_stats", "rt_gpu_reset_stats", "rt_gpu_eval_math",
+]
+
+
+class Options(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "struct_size", "max_segments", "sample_offset", "spp_total", "flags",
+        "band_rows", "band_rank", "band_count")]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.struct_size = C.sizeof(Options)
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "samples", "rays", "shadow_rays", "root_tests", "interior_pops", "leaf_pops",
+        "tri_tests", "tri_hits", "tex_lookups", "rng_draws")] + [
+        ("kernel_ms", C.c_double), ("launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+class GpuError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def lib():
+    """Load librt_gpu.so (raises if it was not built)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise GpuError(f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.rt_gpu_device_count.restype = C.c_int
+        L.rt_gpu_last_error.restype = C.c_char_p
+        L.rt_gpu_scene_create.argtypes = [C.POINTER(T.Scene), C.POINTER(C.c_void_p)]
+        L.rt_gpu_scene_destroy.argtypes = [C.c_void_p]
+        L.rt_gpu_scene_destroy.restype = None
+        L.rt_gpu_scene_set_camera.argtypes = [C.c_void_p, C.POINTER(T.Camera)]
+        L.rt_gpu_render_region.argtypes = [C.c_void_p, C.POINTER(T.Image3f), T.Rect2u, C.c_uint32,
+                                           C.c_uint64, C.POINTER(Options)]
+        L.rt_gpu_render_region_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, T.Rect2u,
+                                                  C.c_uint32, C.c_uint64, C.POINTER(Options), C.c_void_p]
+        L.rt_gpu_normalize_device.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+        L.rt_gpu_render_jobs.argtypes = [C.c_void_p, C.POINTER(T.Job), C.c_uint32, C.POINTER(Options)]
+        L.rt_gpu_find_ray_hit.argtypes = [C.c_void_p, C.POINTER(T.Ray), C.c_uint32, C.c_float,
+                                          C.POINTER(T.RayResult)]
+        L.rt_gpu_quantize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rt_gpu_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.rt_gpu_reset_stats.argtypes = [C.c_void_p]
+        L.rt_gpu_eval_math.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 5
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise GpuError(f"rt_gpu error {rc}: {lib().rt_gpu_last_error().decode()}")
+
+
+def rect(x, y, w, h):
+    r = T.Rect2u()
+    r.point.x, r.point.y, r.size.x, r.size.y = x, y, w, h
+    return r
+
+
+class GpuScene:
+    """A scene resident in HBM (rt_gpu_scene_create / rt_gpu_scene_destroy)."""
+
+    def __init__(self, scene_handle):
+        self._keep = scene_handle
+        self._h = C.c_void_p()
+        _check(lib().rt_gpu_scene_create(scene_handle.ptr, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().rt_gpu_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_region(self, image, region, spp, seed, options=None):
+        """rt_gpu_render_region: host image in, host image out."""
+        _check(lib().rt_gpu_render_region(self._h, C.byref(image), rect(*region), spp, seed,
+                                          C.byref(options) if options is not None else None))
+
+    def render_region_device(self, device_ptr, width, height, region, spp, seed, options=None, stream=0):
+        """rt_gpu_render_region_device: asynchronous render into device memory."""
+        _check(lib().rt_gpu_render_region_device(self._h, device_ptr, width, height, rect(*region), spp, seed,
+                                                 C.byref(options) if options is not None else None,
+                                                 C.c_void_p(stream)))
+
+    def render_jobs(self, jobs, options=None):
+        arr = (T.Job * len(jobs))(*jobs)
+        _check(lib().rt_gpu_render_jobs(self._h, arr, len(jobs),
+                                        C.byref(options) if options is not None else None))
+
+    def find_ray_hit(self, rays, max_distance):
+        """rays: (n, 6) float32 -> ctypes array of RayResult."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        n = len(rays)
+        out = (T.RayResult * n)()
+        _check(lib().rt_gpu_find_ray_hit(self._h, C.cast(rays.ctypes.data, C.POINTER(T.Ray)), n,
+                                         max_distance, out))
+        return out
+
+    def stats(self):
+        st = Stats()
+        _check(lib().rt_gpu_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def reset_stats(self):
+        _check(lib().rt_gpu_reset_stats(self._h))
+
+
+def normalize_device(device_ptr, pixel_count, spp_total, stream=0):
+    _check(lib().rt_gpu_normalize_device(device_ptr, pixel_count, spp_total, C.c_void_p(stream)))
+
+
+def quantize(pixels):
+    pixels = np.ascontiguousarray(pixels, dtype=np.float32)
+    out = np.zeros(pixels.shape, dtype=np.uint8)
+    _check(lib().rt_gpu_quantize(pixels.ctypes.data, pixels.size // 3, out.ctypes.data))
+    return out
+
+
+def eval_math(x, y=None):
+    """Device sin, cos, log, x/y, sqrt of float arrays (self-test hook)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = x.size
+    outs = [np.zeros(n, dtype=np.float32) for _ in range(5)]
+    yp = None
+    if y is not None:
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        yp = y.ctypes.data
+    _check(lib().rt_gpu_eval_math(x.ctypes.data, yp, n, outs[0].ctypes.data, outs[1].ctypes.data,
+                                  outs[2].ctypes.data, outs[3].ctypes.data if y is not None else None,
+                                  outs[4].ctypes.data))
+    return dict(sin=outs[0], cos=outs[1], log=outs[2], div=outs[3] if y is not None else None, sqrt=outs[4])
