@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s and ms/frame of the path-tracing loop on the dog scene.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one whole frame of the workload (config 4 of the benchmark list: the room with
+one textured dog, 1024x1024, 64 samples per pixel, full 64-segment paths) rendered by the
+HIP kernels through the C ABI (include/rt_gpu.h) into device memory.  The scene is resident
+in HBM before the timed region.  With N > 1 (one process per GPU, torch.distributed/RCCL)
+every frame is cut into 8-row bands dealt round-robin to the ranks; each rank renders its
+bands into a packed buffer and one all-gather over xGMI assembles the frame on every rank.
+The frame is the same whatever N is (the generator is keyed by pixel and sample), so this is
+strong scaling of a fixed frame.
+
+Rank 0 prints one JSON line.  `roofline` prices the render kernel against HBM bandwidth with
+the ALGORITHMIC bytes of the traversal (bytes the reference's data structures would move for
+the primitives, boxes, triangles, attributes and texels the kernel actually tested, counted
+by the device), divided by the kernel's own duration measured with HIP events on its stream.
+`cpu_baseline` times the reference itself (compiled from its own sources with its build.sh
+flags, oracle/_ref) on this machine's host cores over a bounded number of samples of the same
+scene; when that library is absent it times the CPU oracle port instead.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+
+
+def algorithmic_bytes(st, scene, pixels):
+    """Bytes the reference's records would move for the work the kernel counted:
+    Light 32, Sphere 20, Plane 20 per primitive tested; Transform 48 + root box 24 per instance
+    root test; two child Mesh_Nodes (2 x 40) per interior pop; Triangle 36 + 3 points 36 per
+    triangle test; 3 normals + 3 uvs (60) per triangle hit; one 12-byte texel per lookup; one
+    12-byte pixel store per pixel."""
+    return (32 * st["light_tests"] + 20 * st["sphere_tests"] + 20 * st["plane_tests"] +
+            72 * st["root_tests"] + 80 * st["interior_pops"] + 72 * st["tri_tests"] +
+            60 * st["tri_hits"] + 12 * st["tex_lookups"] + 12 * pixels)
+
+
+def cpu_baseline(sh, width, height, target_seconds=12.0):
+    """Time the CPU path on this host over a bounded sample of the workload."""
+    import _libs as L
+    from raytracing_amd import host
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    use_ref = L.have_ref("build")
+    tile = 64
+    tiles = ((width + tile - 1) // tile) * ((height + tile - 1) // tile)
+    seeds = (L.T.RandomSerie * tiles)(*[L.serie_from_seed(1000 + i) for i in range(tiles)])
+
+    def run(spp):
+        img, _ = host.new_image(width, height)
+        if use_ref:
+            return L.ref("build").ref_render_tiles(sh.ptr, C.byref(img), spp, tile, threads, seeds)
+        return L.oracle(contract=True).orc_render_tiles(sh.ptr, C.byref(img), spp, tile, threads,
+                                                        L.RNG_AES, L.MATH_LIBM, 64, seeds, 0, None)
+
+    t1 = run(1)
+    spp = int(max(1, min(64, round(target_seconds / max(t1, 1e-3)))))
+    t = run(spp) if spp > 1 else t1
+    # rays per sample of this scene, counted by the oracle on a small frame (same scene, same path rules)
+    st = L.Stats()
+    small, _ = host.new_image(128, 128)
+    L.oracle().orc_render_tiles(sh.ptr, C.byref(small), 4, 64, threads, L.RNG_AES, L.MATH_LIBM, 64,
+                                seeds, 0, C.byref(st))
+    rays_per_sample = st.rays / max(1, st.samples)
+    samples = width * height * spp
+    return {
+        "value": round(samples * rays_per_sample / t / 1e6, 3),
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "reference" if use_ref else "port",
+        "sample": f"{width}x{height} at {spp} spp ({samples / 1e6:.2f} Msamples in {t:.2f} s, "
+                  f"{samples / t / 1e6:.3f} Msamples/s, {rays_per_sample:.2f} rays/sample counted by the oracle), "
+                  f"64x64 tiles on an atomic queue over {threads} threads, render only",
+        "ms_per_frame_64spp_extrapolated": round(1e3 * t * 64 / spp, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--scene", default="dog_room")
+    ap.add_argument("--max-segments", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from raytracing_amd import gpu, scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, spp = args.width, args.height, args.spp
+    band = 8
+    sh = scenes.CONFIGS[args.scene]()
+    g = gpu.GpuScene(sh)                               # flatten + upload: outside the timed region
+    stream = torch.cuda.current_stream().cuda_stream
+
+    if world > 1:
+        assert H % (band * world) == 0, "height must be a multiple of 8 * ranks"
+        rows = H // world
+        mine = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")
+        gathered = torch.zeros((world, rows, W, 3), dtype=torch.float32, device="cuda")
+        opts = gpu.Options(max_segments=args.max_segments, band_rows=band, band_rank=rank, band_count=world,
+                           flags=gpu.FLAG_COMPACT_BANDS)
+    else:
+        mine = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        gathered = None
+        opts = gpu.Options(max_segments=args.max_segments)
+    frame = None
+
+    def step(seed, options=opts):
+        nonlocal frame
+        g.render_region_device(mine.data_ptr(), W, H, (0, 0, W, H), spp, seed, options, stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, mine)
+            # rank r holds bands r, r+world, ...: interleave them back into image order
+            frame = gathered.view(world, H // (band * world), band, W, 3).permute(1, 0, 2, 3, 4).reshape(H, W, 3)
+        else:
+            frame = mine
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(10_000 + i)
+    fence()
+    g.reset_stats()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = g.stats()
+
+    # max over ranks of the time, sum over ranks of the rays
+    rays = float(st["rays"])
+    kernel_ms = st["kernel_ms"] / max(1, st["launches"])
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        r = torch.tensor([rays], dtype=torch.float64, device="cuda")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        elapsed, kernel_ms, rays = float(t[0]), float(t[1]), float(r[0])
+
+    # algorithmic bytes of ONE launch: the same frame (seed 0) with the detailed counters on, untimed
+    g.reset_stats()
+    step(0, gpu.Options(max_segments=args.max_segments, flags=opts.flags | gpu.FLAG_DETAILED_STATS,
+                        band_rows=opts.band_rows, band_rank=opts.band_rank, band_count=opts.band_count))
+    torch.cuda.synchronize()
+    det = g.stats()
+    own_pixels = (H // world) * W
+    abytes = algorithmic_bytes(det, sh, own_pixels)
+    checksum = float(frame.double().sum().item())
+
+    if rank == 0:
+        achieved = abytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (all bounces), dog.obj 1024x1024 64 spp",
+            "value": round(rays / elapsed / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "dog model + texture from the parsed-asset fixtures in tests/golden, room scene from the "
+                    "reference's main(); random numbers from the counter generator, seed = step index",
+            "config": {
+                "workload": f"{args.scene} {W}x{H} {spp} spp, {args.max_segments}-segment paths "
+                            "(config 4: dog.obj textured, BVH, indirect lighting)",
+                "rays_per_step": round(rays / args.steps),
+                "rays_per_sample": round(rays / args.steps / (W * H * spp), 3),
+                "ms_per_frame": round(1e3 * elapsed / args.steps, 3),
+                "split": "8-row bands round-robin + all-gather" if world > 1 else "single device",
+                "frame_checksum_seed0": checksum,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel": "rt_render_pixels_kernel",
+                "kernel_ms": round(kernel_ms, 3),
+                "algorithmic_bytes_per_launch": int(abytes),
+                "algorithmic_bytes_per_ray": round(abytes / max(1, det["rays"]), 1),
+                "counted": {k: int(det[k]) for k in ("rays", "shadow_rays", "root_tests", "interior_pops",
+                                                     "tri_tests", "tri_hits", "tex_lookups", "light_tests",
+                                                     "sphere_tests", "plane_tests")},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(sh, W, H)
+            except Exception as e:  # the baseline is a side measurement; never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    g.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,7 +73,8 @@ typedef struct rt_gpu_options {
 typedef struct rt_gpu_stats {
     uint64_t samples, rays, shadow_rays;
     uint64_t root_tests, interior_pops, leaf_pops, tri_tests, tri_hits, tex_lookups, rng_draws;
-                             /* the second line only with RT_GPU_FLAG_DETAILED_STATS */
+    uint64_t light_tests, sphere_tests, plane_tests;
+                             /* all but the first line only with RT_GPU_FLAG_DETAILED_STATS */
     double   kernel_ms;      /* device time of the render kernels (HIP events) */
     uint32_t launches;
     uint32_t reserved;

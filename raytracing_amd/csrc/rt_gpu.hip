@@ -18,7 +18,7 @@
 #include "rt_trace.hpp"
 
 #define RT_BLOCK 256                 /* 4 waves; a wave owns an 8x8 pixel block */
-#define RT_STAT_WORDS 10
+#define RT_STAT_WORDS 13
 
 /* ------------------------------------------------------------------------ */
 /* kernels                                                                   */
@@ -648,7 +648,7 @@ int rt_gpu_get_stats(rt_gpu_scene *s, rt_gpu_stats *out)
     out->samples = w[0] ? w[0] : s->samples;
     out->rays = w[1]; out->shadow_rays = w[2]; out->root_tests = w[3]; out->interior_pops = w[4];
     out->leaf_pops = w[5]; out->tri_tests = w[6]; out->tri_hits = w[7]; out->tex_lookups = w[8];
-    out->rng_draws = w[9];
+    out->rng_draws = w[9]; out->light_tests = w[10]; out->sphere_tests = w[11]; out->plane_tests = w[12];
     out->kernel_ms = s->kernel_ms;
     out->launches = s->launches;
     return RT_GPU_OK;

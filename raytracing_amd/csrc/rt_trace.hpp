@@ -63,7 +63,7 @@ __device__ __forceinline__ f3 blend(f3 a, f3 b, f3 c, f3 w)
 /* ------------------------------------------------------------------ counters */
 struct Counters {
     uint32_t samples, rays, shadow_rays, root_tests, interior_pops, leaf_pops, tri_tests, tri_hits,
-             tex_lookups, rng_draws;
+             tex_lookups, rng_draws, light_tests, sphere_tests, plane_tests;
 };
 
 /* ------------------------------------------------------------------ generators */
@@ -206,6 +206,7 @@ __device__ __forceinline__ void closest_hit(const rt_dev_scene &S, f3 o, f3 d, f
     for (int i = 0; i < S.light_count; i++) {
         const rt_dev_light &l = S.lights[i];
         float t;
+        if (STATS) cn.light_tests++;
         if (ball(ld3(l.c), l.radius, o, d, h.t, t, h.entered)) {
             h.type = HIT_LIGHT; h.id = (uint32_t)i; h.t = t;
             if (SHADOW) return;
@@ -214,6 +215,7 @@ __device__ __forceinline__ void closest_hit(const rt_dev_scene &S, f3 o, f3 d, f
     for (int i = 0; i < S.sphere_count; i++) {
         const rt_dev_sphere &s = S.spheres[i];
         float t;
+        if (STATS) cn.sphere_tests++;
         if (ball(ld3(s.c), s.radius, o, d, h.t, t, h.entered)) {
             h.type = HIT_SPHERE; h.id = (uint32_t)i; h.t = t; h.material = s.material;
             if (SHADOW) return;
@@ -222,6 +224,7 @@ __device__ __forceinline__ void closest_hit(const rt_dev_scene &S, f3 o, f3 d, f
     for (int i = 0; i < S.plane_count; i++) {                        /* src/main.c:355-369 */
         const rt_dev_plane &p = S.planes[i];
         f3 n = ld3(p.n);
+        if (STATS) cn.plane_tests++;
         float t = (p.d - dot(o, n)) / dot(d, n);
         if (t < 1e-3f) continue;
         if (t > h.t) continue;

@@ -40,7 +40,7 @@ class Options(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "samples", "rays", "shadow_rays", "root_tests", "interior_pops", "leaf_pops",
-        "tri_tests", "tri_hits", "tex_lookups", "rng_draws")] + [
+        "tri_tests", "tri_hits", "tex_lookups", "rng_draws", "light_tests", "sphere_tests", "plane_tests")] + [
         ("kernel_ms", C.c_double), ("launches", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
