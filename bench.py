@@ -100,7 +100,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from raytracing_amd import gpu, scenes
+    from raytracing_amd import gpu, multi_gpu, scenes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -117,16 +117,15 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W, H, spp = args.width, args.height, args.spp
-    band = 8
+    band = multi_gpu.BAND_ROWS
     sh = scenes.CONFIGS[args.scene]()
     g = gpu.GpuScene(sh)                               # flatten + upload: outside the timed region
     stream = torch.cuda.current_stream().cuda_stream
 
     if world > 1:
-        assert H % (band * world) == 0, "height must be a multiple of 8 * ranks"
-        rows = H // world
+        rows = multi_gpu.packed_rows(world, H, band)
         mine = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")
-        gathered = torch.zeros((world, rows, W, 3), dtype=torch.float32, device="cuda")
+        gathered = torch.zeros((world * rows, W, 3), dtype=torch.float32, device="cuda")
         opts = gpu.Options(max_segments=args.max_segments, band_rows=band, band_rank=rank, band_count=world,
                            flags=gpu.FLAG_COMPACT_BANDS)
     else:
@@ -140,8 +139,7 @@ def main():
         g.render_region_device(mine.data_ptr(), W, H, (0, 0, W, H), spp, seed, options, stream)
         if world > 1:
             dist.all_gather_into_tensor(gathered, mine)
-            # rank r holds bands r, r+world, ...: interleave them back into image order
-            frame = gathered.view(world, H // (band * world), band, W, 3).permute(1, 0, 2, 3, 4).reshape(H, W, 3)
+            frame = multi_gpu.assemble(gathered, world, H, W, band)
         else:
             frame = mine
 

@@ -4,6 +4,7 @@ There is no fallback: if the HIP library is missing or no GPU is visible the
 calls raise.  Everything here is plumbing around the C entry points.
 """
 import ctypes as C
+import importlib.util
 import os
 
 import numpy as np
@@ -61,6 +62,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise GpuError(f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc` "
                            "(or __graft_entry__.build()); there is no CPU fallback")
+        # A process must hold ONE HIP runtime.  PyTorch wheels bundle their own libamdhip64 /
+        # libhsa-runtime64; if this library pulled in /opt/rocm's copy first, torch would later find
+        # no GPU.  So when torch is installed, let it load its runtime first: the dynamic linker then
+        # resolves this library's libamdhip64.so dependency to the copy already in the process.
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         L.rt_gpu_device_count.restype = C.c_int
         L.rt_gpu_last_error.restype = C.c_char_p

