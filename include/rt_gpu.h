@@ -74,6 +74,9 @@ typedef struct rt_gpu_stats {
     uint64_t samples, rays, shadow_rays;
     uint64_t root_tests, interior_pops, leaf_pops, tri_tests, tri_hits, tex_lookups, rng_draws;
     uint64_t light_tests, sphere_tests, plane_tests;
+    uint64_t shade_steps, pop_steps, tri_steps;  /* wave-level scheduler steps of each kind ...          */
+    uint64_t shade_lanes, pop_lanes, tri_lanes;  /* ... and the lanes that took part in them (of 64 each) */
+    uint64_t tree_entries;                       /* (ray, instance) pairs whose tree was entered          */
                              /* all but the first line only with RT_GPU_FLAG_DETAILED_STATS */
     double   kernel_ms;      /* device time of the render kernels (HIP events) */
     uint32_t launches;

@@ -25,6 +25,7 @@
  *   rng:   ORC_RNG_AES      the reference's own serial 256-bit AES-DEC stream
  *          ORC_RNG_COUNTER  Threefry-2x32-20 keyed by (seed, pixel, sample), the
  *                           generator the GPU kernels use for parallel sampling
+ *                           (restated here independently of the device code)
  *   math:  ORC_MATH_LIBM     cosf/sinf/logf from the C library (as the reference)
  *          ORC_MATH_PORTABLE rt_math_portable.h (shared with the GPU kernels)
  */
@@ -188,8 +189,8 @@ typedef struct orc_ctx {
     orc_stats *stats;
 } orc_ctx;
 
-/* counter mode: a sample's key is Threefry(seed; pixel, sample); draw d of
- * that sample is Threefry(sample key; d, 0). */
+/* counter mode: a sample's key is K = Threefry(seed; pixel, sample); draw 0 of
+ * the sample is K itself, draw d >= 1 is Threefry(K; d, 0). */
 static void ctx_begin_sample(orc_ctx *cx, uint32_t pixel, uint32_t sample)
 {
     uint32_t ctr[2] = { pixel, sample };
@@ -220,8 +221,9 @@ static void ctx_uniform4(orc_ctx *cx, float lo, float hi, float out[4])
             w[i] = a ^ b;
         }
     } else {
-        uint32_t ctr[2] = { cx->draw++, 0 };
-        threefry2x32_20(cx->sample_key, ctr, w);
+        if (cx->draw == 0) { w[0] = cx->sample_key[0]; w[1] = cx->sample_key[1]; }
+        else { uint32_t ctr[2] = { cx->draw, 0 }; threefry2x32_20(cx->sample_key, ctr, w); }
+        cx->draw++;
         w[2] = w[3] = 0;     /* lanes 2 and 3 are never consumed */
     }
     const float scale = hi - lo;

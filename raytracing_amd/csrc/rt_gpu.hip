@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -18,7 +19,13 @@
 #include "rt_trace.hpp"
 
 #define RT_BLOCK 256                 /* 4 waves; a wave owns an 8x8 pixel block */
-#define RT_STAT_WORDS 13
+#define RT_STAT_WORDS 20
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 2          /* register budget of the render kernel: 512 / this many VGPRs */
+#endif
+#ifndef RT_SHADE_WEIGHT
+#define RT_SHADE_WEIGHT 16            /* scheduler: weight of a lane that wants a shade step, in 1/16ths */
+#endif
 
 /* ------------------------------------------------------------------------ */
 /* kernels                                                                   */
@@ -32,11 +39,12 @@ struct RenderParams {
     uint32_t x0, y0, w, h;           /* region */
     uint32_t blocks_x, block_rows;   /* 8x8 pixel blocks this launch walks */
     uint32_t band_blocks, band_rank, band_count;   /* 0 band_blocks = no split */
-    uint32_t out_pitch;              /* pixels per output row */
-    uint32_t compact;                /* output rows are this rank's rows, packed */
+    float   *samples;                /* scratch: [sample of this launch][wave][pixel of the 8x8 block] RGB */
+    uint32_t first_sample, launch_spp;   /* this launch renders samples first_sample .. +launch_spp of the call */
     uint32_t spp, sample_offset, seed0, seed1;
     int      max_segments;
     uint32_t accumulate;
+    int      shade_weight;           /* scheduler weight, see rt::PathMachine::run */
     float    norm, half_w, half_h;
 };
 
@@ -65,50 +73,105 @@ __device__ __forceinline__ void flush_counters(const rt::Counters &cn, uint64_t 
     }
 }
 
-/* One lane = one pixel, all of its samples in order (the running sum of a pixel
- * is a sequential float sum, src/main.c:785).  One wave = one 8x8 pixel block. */
+/* One wave = one 8x8 pixel block and ALL its (pixel, sample) work items of this
+ * launch; lanes take items from a wave-local counter as they become free, so no
+ * lane waits for a neighbour whose pixel needs longer paths.  Sample values go
+ * to a scratch buffer; rt_resolve_kernel adds them up per pixel in sample order
+ * (the host's per-pixel sum is a sequential float sum, src/main.c:785). */
 template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK)
+__global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 rt_render_pixels_kernel(const RenderParams P)
 {
     extern __shared__ uint32_t lds[];
     rt::Stack stk; stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK;
+    uint32_t *next_item = lds + RT_BLOCK * P.S.stack_cap + (threadIdx.x >> 6);   /* one word per wave */
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
 
     const uint32_t wave = (blockIdx.x * RT_BLOCK + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
-    bool active = wave < P.blocks_x * P.block_rows;
-    uint32_t bx = 0, by = 0, own_row = 0;
-    if (active) {
+    const bool wave_live = wave < P.blocks_x * P.block_rows;
+    uint32_t bx = 0, by = 0;
+    if (wave_live) {
         bx = wave % P.blocks_x;
-        own_row = wave / P.blocks_x;
-        by = own_row;
+        by = wave / P.blocks_x;
         if (P.band_blocks) {
-            uint32_t k = own_row / P.band_blocks, in = own_row % P.band_blocks;
+            uint32_t k = by / P.band_blocks, in = by % P.band_blocks;
             by = (k * P.band_count + P.band_rank) * P.band_blocks + in;
         }
     }
-    const uint32_t lx = bx * 8 + (lane & 7), ly = by * 8 + (lane >> 3);
-    active = active && lx < P.w && ly < P.h;
-    if (active) {
-        const uint32_t x = P.x0 + lx, y = P.y0 + ly;
-        const uint32_t pixel = P.width * y + x;
-        size_t out = P.compact ? ((size_t)(own_row * 8 + (lane >> 3)) * P.out_pitch + lx)
-                               : ((size_t)y * P.out_pitch + x);
-        float *dst = P.pixels + 3 * out;
-        rt::f3 total = rt::mk(0, 0, 0);
-        if (P.accumulate) total = rt::mk(dst[0], dst[1], dst[2]);
-        rt::CounterRng rng;
-        for (uint32_t i = 0; i < P.spp; i++) {
-            rng.begin(P.seed0, P.seed1, pixel, P.sample_offset + i);
-            rt::f3 c = rt::sample_pixel<rt::CounterRng, STATS>(P.S, rng, stk, x, y, P.half_w, P.half_h,
-                                                                 P.max_segments, cn);
-            total = rt::add(total, c);
+    if (lane == 0) *next_item = 0;
+    const uint32_t items = wave_live ? 64u * P.launch_spp : 0u;
+    float *my_samples = P.samples + 3 * (size_t)wave * 64;
+    const size_t sample_stride = 3 * (size_t)P.blocks_x * P.block_rows * 64;
+
+    rt::PathMachine<rt::CounterRng, STATS> pm(P.S, stk, cn);
+    pm.half_w = P.half_w; pm.half_h = P.half_h; pm.max_segments = P.max_segments;
+    pm.rng.seed0 = P.seed0; pm.rng.seed1 = P.seed1;
+    uint32_t item = 0;
+
+    /* next work item of this wave for this lane: item k = pixel k%64 of the block, sample k/64 */
+    auto take_item = [&]() {
+        for (;;) {
+            item = atomicAdd(next_item, 1u);
+            if (item >= items) { pm.phase = rt::PH_DEAD; return; }
+            const uint32_t p = item & 63u;
+            const uint32_t lx = bx * 8 + (p & 7), ly = by * 8 + (p >> 3);
+            if (lx < P.w && ly < P.h) {
+                pm.x = P.x0 + lx; pm.y = P.y0 + ly;
+                pm.start_path();
+                pm.rng.begin(P.width * pm.y + pm.x, P.sample_offset + P.first_sample + (item >> 6));
+                return;
+            }
         }
-        if (!P.accumulate) total = rt::scale(total, P.norm);
-        dst[0] = total.x; dst[1] = total.y; dst[2] = total.z;
-    }
+    };
+    take_item();
+
+    pm.run(P.shade_weight, [&]() {
+        const rt::f3 c = pm.path_value();
+        float *dst = my_samples + (size_t)(item >> 6) * sample_stride + 3 * (item & 63u);
+        dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
+        take_item();
+    });
     flush_counters<STATS>(cn, P.stats);
+}
+
+/* per pixel: running sum += its samples of this launch, in sample order; the
+ * last launch of a call applies the host's final factor (src/main.c:788) */
+struct ResolveParams {
+    const float *samples; float *pixels;
+    uint32_t x0, y0, w, h;
+    uint32_t blocks_x, block_rows, band_blocks, band_rank, band_count;
+    uint32_t out_pitch, compact;
+    uint32_t launch_spp;
+    uint32_t start_from_pixels;      /* 1: the running sum starts from the stored pixel */
+    uint32_t finish;                 /* 1: multiply by norm */
+    float norm;
+};
+
+__global__ void __launch_bounds__(RT_BLOCK)
+rt_resolve_kernel(const ResolveParams P)
+{
+    const uint32_t wave = (blockIdx.x * RT_BLOCK + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (wave >= P.blocks_x * P.block_rows) return;
+    uint32_t bx = wave % P.blocks_x, own_row = wave / P.blocks_x, by = own_row;
+    if (P.band_blocks) {
+        uint32_t k = own_row / P.band_blocks, in = own_row % P.band_blocks;
+        by = (k * P.band_count + P.band_rank) * P.band_blocks + in;
+    }
+    const uint32_t lx = bx * 8 + (lane & 7), ly = by * 8 + (lane >> 3);
+    if (!(lx < P.w && ly < P.h)) return;
+    const size_t out = P.compact ? ((size_t)(own_row * 8 + (lane >> 3)) * P.out_pitch + lx)
+                                 : ((size_t)(P.y0 + ly) * P.out_pitch + (P.x0 + lx));
+    float *dst = P.pixels + 3 * out;
+    rt::f3 total = rt::mk(0, 0, 0);
+    if (P.start_from_pixels) total = rt::mk(dst[0], dst[1], dst[2]);
+    const float *src = P.samples + 3 * ((size_t)wave * 64 + lane);
+    const size_t sample_stride = 3 * (size_t)P.blocks_x * P.block_rows * 64;
+    for (uint32_t i = 0; i < P.launch_spp; i++, src += sample_stride)
+        total = rt::add(total, rt::mk(src[0], src[1], src[2]));
+    if (P.finish) total = rt::scale(total, P.norm);
+    dst[0] = total.x; dst[1] = total.y; dst[2] = total.z;
 }
 
 /* ---- replay of host jobs: one lane = one Job (src/main.h:65-72), walked in the
@@ -136,24 +199,37 @@ rt_render_jobs_kernel(const JobParams P)
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
 
     const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (j < P.job_count) {
-        const DevJob job = P.jobs[j];
-        rt::AesRng rng; rng.td = td;
-        for (int k = 0; k < 4; k++) { rng.a[k] = job.serie[k]; rng.b[k] = job.serie[4 + k]; }
-        const float norm = job.norm;
-        for (uint32_t y = job.y0; y < job.y0 + job.h; y++)
-            for (uint32_t x = job.x0; x < job.x0 + job.w; x++) {
-                rt::f3 total = rt::mk(0, 0, 0);
-                for (uint32_t i = 0; i < job.spp; i++) {
-                    rt::f3 c = rt::sample_pixel<rt::AesRng, STATS>(P.S, rng, stk, x, y, P.half_w, P.half_h,
-                                                                     P.max_segments, cn);
-                    total = rt::add(total, c);
-                }
-                total = rt::scale(total, norm);
-                float *dst = P.pixels + 3 * ((size_t)P.width * y + x);
-                dst[0] = total.x; dst[1] = total.y; dst[2] = total.z;
-            }
-    }
+    bool live = j < P.job_count;
+    DevJob job;
+    memset(&job, 0, sizeof(job));
+    if (live) job = P.jobs[j];
+    live = live && job.w && job.h;
+
+    rt::PathMachine<rt::AesRng, STATS> pm(P.S, stk, cn);
+    pm.half_w = P.half_w; pm.half_h = P.half_h; pm.max_segments = P.max_segments;
+    pm.rng.td = td;
+    for (int k = 0; k < 4; k++) { pm.rng.a[k] = job.serie[k]; pm.rng.b[k] = job.serie[4 + k]; }
+    pm.x = job.x0; pm.y = job.y0;
+    rt::f3 total = rt::mk(0, 0, 0);
+    uint32_t s = 0;
+    pm.start_path();
+    if (!live) pm.phase = rt::PH_DEAD;
+
+    pm.run(RT_SHADE_WEIGHT, [&]() {
+        total = rt::add(total, pm.path_value());
+        s++;
+        pm.start_path();
+        if (s == job.spp) {                     /* pixel finished: store, move on in the host's order */
+            total = rt::scale(total, job.norm);
+            float *dst = P.pixels + 3 * ((size_t)P.width * pm.y + pm.x);
+            dst[0] = total.x; dst[1] = total.y; dst[2] = total.z;
+            total = rt::mk(0, 0, 0);
+            s = 0;
+            pm.x++;
+            if (pm.x == job.x0 + job.w) { pm.x = job.x0; pm.y++; }
+            if (pm.y == job.y0 + job.h) pm.phase = rt::PH_DEAD;
+        }
+    });
     flush_counters<STATS>(cn, P.stats);
 }
 
@@ -177,7 +253,7 @@ rt_find_hit_kernel(const HitParams P)
     if (i < P.count) {
         rt::f3 o = rt::ld3(P.rays + 6 * i), d = rt::ld3(P.rays + 6 * i + 3);
         rt::Hit h;
-        rt::closest_hit<false, true>(P.S, o, d, P.max_distance, stk, h, cn);
+        rt::closest_hit<true>(P.S, o, d, P.max_distance, false, stk, h, cn);
         rt::Surface sf;
         rt::surface_of<true>(P.S, o, d, h, sf, cn);
         uint32_t *w = reinterpret_cast<uint32_t *>(P.results + 72 * (size_t)i);
@@ -244,6 +320,7 @@ struct rt_gpu_scene {
     uint64_t *d_stats = nullptr;
     uint32_t *d_aes_table = nullptr;
     float *d_frame = nullptr; size_t frame_floats = 0;
+    float *d_samples = nullptr; uint64_t scratch_bytes = 0;   /* per-sample values between trace and resolve */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timers;   /* pending kernel timings */
     std::vector<hipEvent_t> spare_events;
     double kernel_ms = 0.0;
@@ -308,6 +385,7 @@ void rt_gpu_scene_destroy(rt_gpu_scene *s)
     (void)hipDeviceSynchronize();
     for (void *p : s->allocations) (void)hipFree(p);
     if (s->d_frame) (void)hipFree(s->d_frame);
+    if (s->d_samples) (void)hipFree(s->d_samples);
     for (auto &t : s->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     for (auto e : s->spare_events) (void)hipEventDestroy(e);
     delete s;
@@ -327,7 +405,7 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
         if (hipGetDevice(&s->device) != hipSuccess) { rc = fail(RT_GPU_ERR_DEVICE, "hipGetDevice failed"); break; }
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) { rc = fail(RT_GPU_ERR_DEVICE, "hipGetDeviceProperties failed"); break; }
-        size_t lds_need = (size_t)RT_BLOCK * flat.stack_cap * 4 + 1024;
+        size_t lds_need = (size_t)RT_BLOCK * flat.stack_cap * 4 + 1024 + 64;
         if (lds_need > prop.sharedMemPerBlock) {
             rc = fail(RT_GPU_ERR_SCENE, "box tree too deep for the LDS traversal stack (" + std::to_string(flat.stack_cap) + " levels)");
             break;
@@ -375,6 +453,16 @@ int rt_gpu_scene_set_camera(rt_gpu_scene *s, const void *camera)
     rt_flatten_camera(c, s->dev.cam);
     s->field_of_view = c->field_of_view;
     return RT_GPU_OK;
+}
+
+static int ensure_scratch(rt_gpu_scene *s, uint64_t bytes)
+{
+    if (s->scratch_bytes >= bytes) return 0;
+    if (s->d_samples) { (void)hipDeviceSynchronize(); (void)hipFree(s->d_samples); s->d_samples = nullptr; s->scratch_bytes = 0; }
+    if (hipMalloc(reinterpret_cast<void **>(&s->d_samples), bytes) != hipSuccess)
+        return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the sample scratch (" + std::to_string(bytes >> 20) + " MiB)");
+    s->scratch_bytes = bytes;
+    return 0;
 }
 
 static hipEvent_t take_event(rt_gpu_scene *s)
@@ -447,33 +535,61 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     const uint32_t flags = o ? o->flags : 0;
     P.S = s->dev;
     P.S.cam.focal = rt_camera_focal(s->field_of_view, height);
-    P.pixels = device_pixels; P.stats = s->d_stats;
+    P.stats = s->d_stats;
     P.width = width; P.height = height;
     P.x0 = region.point.x; P.y0 = region.point.y; P.w = region.size.x; P.h = region.size.y;
-    P.compact = (flags & RT_GPU_FLAG_COMPACT_BANDS) ? 1 : 0;
-    P.out_pitch = P.compact ? region.size.x : width;
-    P.spp = spp; P.sample_offset = o ? o->sample_offset : 0;
+    P.sample_offset = o ? o->sample_offset : 0;
     P.seed0 = (uint32_t)seed; P.seed1 = (uint32_t)(seed >> 32);
     P.max_segments = (o && o->max_segments) ? (int)o->max_segments : 64;
-    P.accumulate = (flags & RT_GPU_FLAG_ACCUMULATE) ? 1 : 0;
-    P.norm = rt_pixel_norm((o && o->spp_total) ? o->spp_total : spp);
     P.half_w = (float)width / 2.0f; P.half_h = (float)height / 2.0f;
+    P.shade_weight = RT_SHADE_WEIGHT;
+    if (const char *e = getenv("RT_GPU_SHADE_WEIGHT")) P.shade_weight = atoi(e);   /* tuning aid */
     if (P.block_rows == 0) return RT_GPU_OK;
 
-    const uint64_t waves = (uint64_t)P.blocks_x * P.block_rows;
-    const uint32_t grid = (uint32_t)((waves * 64 + RT_BLOCK - 1) / RT_BLOCK);
-    const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
+    ResolveParams R;
+    memset(&R, 0, sizeof(R));
+    R.pixels = device_pixels;
+    R.x0 = P.x0; R.y0 = P.y0; R.w = P.w; R.h = P.h;
+    R.blocks_x = P.blocks_x; R.block_rows = P.block_rows;
+    R.band_blocks = P.band_blocks; R.band_rank = P.band_rank; R.band_count = P.band_count;
+    R.compact = (flags & RT_GPU_FLAG_COMPACT_BANDS) ? 1 : 0;
+    R.out_pitch = R.compact ? region.size.x : width;
+    R.norm = rt_pixel_norm((o && o->spp_total) ? o->spp_total : spp);
+    const bool accumulate = (flags & RT_GPU_FLAG_ACCUMULATE) != 0;
 
-    hipEvent_t e0 = take_event(s), e1 = take_event(s);
-    if (e0 && e1) RT_HIP(hipEventRecord(e0, stream));
-    if (flags & RT_GPU_FLAG_DETAILED_STATS)
-        hipLaunchKernelGGL(rt_render_pixels_kernel<true>, dim3(grid), dim3(RT_BLOCK), lds, stream, P);
-    else
-        hipLaunchKernelGGL(rt_render_pixels_kernel<false>, dim3(grid), dim3(RT_BLOCK), lds, stream, P);
-    RT_HIP(hipGetLastError());
-    if (e0 && e1) { RT_HIP(hipEventRecord(e1, stream)); s->timers.emplace_back(e0, e1); }
+    /* sample scratch: 12 bytes per (pixel slot, sample); a call is cut into launches that fit the budget */
+    const uint64_t waves = (uint64_t)P.blocks_x * P.block_rows;
+    const uint64_t bytes_per_sample = waves * 64 * 12;
+    uint64_t budget = (uint64_t)4096 << 20;
+    if (const char *e = getenv("RT_GPU_SCRATCH_MB")) budget = (uint64_t)atoll(e) << 20;
+    uint64_t per_launch = budget / bytes_per_sample;
+    if (per_launch < 1) per_launch = 1;
+    if (per_launch > spp) per_launch = spp;
+    rc = ensure_scratch(s, per_launch * bytes_per_sample);
+    if (rc) return rc;
+    P.samples = s->d_samples; R.samples = s->d_samples;
+
+    const uint32_t grid = (uint32_t)((waves * 64 + RT_BLOCK - 1) / RT_BLOCK);
+    const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4 + 4 * (RT_BLOCK / 64);
+    for (uint32_t first = 0; first < spp; first += (uint32_t)per_launch) {
+        P.first_sample = first;
+        P.launch_spp = (uint32_t)(spp - first < per_launch ? spp - first : per_launch);
+        hipEvent_t e0 = take_event(s), e1 = take_event(s);
+        if (e0 && e1) RT_HIP(hipEventRecord(e0, stream));
+        if (flags & RT_GPU_FLAG_DETAILED_STATS)
+            hipLaunchKernelGGL(rt_render_pixels_kernel<true>, dim3(grid), dim3(RT_BLOCK), lds, stream, P);
+        else
+            hipLaunchKernelGGL(rt_render_pixels_kernel<false>, dim3(grid), dim3(RT_BLOCK), lds, stream, P);
+        RT_HIP(hipGetLastError());
+        if (e0 && e1) { RT_HIP(hipEventRecord(e1, stream)); s->timers.emplace_back(e0, e1); }
+        R.launch_spp = P.launch_spp;
+        R.start_from_pixels = (accumulate || first > 0) ? 1 : 0;
+        R.finish = (!accumulate && first + P.launch_spp >= spp) ? 1 : 0;
+        hipLaunchKernelGGL(rt_resolve_kernel, dim3(grid), dim3(RT_BLOCK), 0, stream, R);
+        RT_HIP(hipGetLastError());
+        s->launches++;
+    }
     if (s->timers.size() > 2048) settle_timers(s);
-    s->launches++;
     s->samples += (uint64_t)spp * own_rows * region.size.x;
     return RT_GPU_OK;
 }
@@ -649,6 +765,8 @@ int rt_gpu_get_stats(rt_gpu_scene *s, rt_gpu_stats *out)
     out->rays = w[1]; out->shadow_rays = w[2]; out->root_tests = w[3]; out->interior_pops = w[4];
     out->leaf_pops = w[5]; out->tri_tests = w[6]; out->tri_hits = w[7]; out->tex_lookups = w[8];
     out->rng_draws = w[9]; out->light_tests = w[10]; out->sphere_tests = w[11]; out->plane_tests = w[12];
+    out->shade_steps = w[13]; out->pop_steps = w[14]; out->tri_steps = w[15];
+    out->shade_lanes = w[16]; out->pop_lanes = w[17]; out->tri_lanes = w[18]; out->tree_entries = w[19];
     out->kernel_ms = s->kernel_ms;
     out->launches = s->launches;
     return RT_GPU_OK;

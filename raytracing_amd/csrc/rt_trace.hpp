@@ -63,7 +63,9 @@ __device__ __forceinline__ f3 blend(f3 a, f3 b, f3 c, f3 w)
 /* ------------------------------------------------------------------ counters */
 struct Counters {
     uint32_t samples, rays, shadow_rays, root_tests, interior_pops, leaf_pops, tri_tests, tri_hits,
-             tex_lookups, rng_draws, light_tests, sphere_tests, plane_tests;
+             tex_lookups, rng_draws, light_tests, sphere_tests, plane_tests,
+             shade_steps, pop_steps, tri_steps, shade_lanes, pop_lanes, tri_lanes,   /* scheduler: wave steps (lane 0) and lanes taking part */
+             tree_entries;                                                          /* instance trees entered */
 };
 
 /* ------------------------------------------------------------------ generators */
@@ -99,21 +101,25 @@ __device__ __forceinline__ float bits_to_unit(uint32_t w)
     return __uint_as_float((w & 0x007FFFFFu) | 0x3F800000u) - 1.0f;
 }
 
-/* Counter generator: the key of a sample is Threefry(seed; pixel, sample);
- * draw d of that sample is Threefry(sample key; d, 0).  Nothing is carried
- * from one sample to the next, so any lane can compute any sample. */
+/* Counter generator.  The key of a sample is K = Threefry(seed; pixel, sample).
+ * Draw 0 of the sample IS K (its two words), draw d >= 1 is Threefry(K; d, 0).
+ * Nothing is carried from one sample to the next, so any lane can compute any
+ * sample; and every draw, the first included, costs exactly one Threefry call
+ * (no divergent "new sample" branch inside a wave). */
 struct CounterRng {
-    uint32_t k0, k1, draw;
-    __device__ __forceinline__ void begin(uint32_t seed0, uint32_t seed1, uint32_t pixel, uint32_t sample)
+    uint32_t seed0, seed1;        /* wave-uniform */
+    uint32_t k0, k1, c0, c1;
+    bool fresh;
+    __device__ __forceinline__ void begin(uint32_t pixel, uint32_t sample)
     {
-        threefry2x32_20(seed0, seed1, pixel, sample, k0, k1);
-        draw = 0;
+        c0 = pixel; c1 = sample; fresh = true;
     }
     __device__ __forceinline__ void uniform2(float &u0, float &u1)
     {
         uint32_t a, b;
-        threefry2x32_20(k0, k1, draw, 0u, a, b);
-        draw++;
+        threefry2x32_20(fresh ? seed0 : k0, fresh ? seed1 : k1, c0, c1, a, b);
+        if (fresh) { k0 = a; k1 = b; c0 = 1u; c1 = 0u; fresh = false; }
+        else c0++;
         u0 = bits_to_unit(a); u1 = bits_to_unit(b);
     }
 };
@@ -192,16 +198,36 @@ __device__ __forceinline__ bool ball(f3 center, float radius, f3 o, f3 d, float 
     return true;
 }
 
-/* SHADOW: only "is anything within tmax" is wanted, so the first accepted
- * primitive ends the query (the host runs the full query and reads .hit). */
-template <bool SHADOW, bool STATS>
-__device__ __forceinline__ void closest_hit(const rt_dev_scene &S, f3 o, f3 d, float tmax, Stack stk,
+/* ---- a closest-hit query in three resumable pieces ------------------------
+ *
+ * find_ray_hit (src/main.c:264-485) tests lights, spheres, planes, then walks
+ * each mesh instance's tree.  The tree walk is the only part whose length
+ * differs wildly between the lanes of a wave, so it is cut into micro-steps
+ * (one node pop or one triangle test) that a lane can be parked in between:
+ *   query_begin   lights, spheres, planes                    (:280-369)
+ *   query_scan    next instance whose root box the ray enters (:372-395)
+ *   query_step    one pop / one triangle of that instance     (:397-483)
+ * Per ray the sequence of operations is the host's; any_hit (shadow rays: the
+ * host only reads .hit of those) ends the query at the first accepted
+ * primitive.
+ */
+struct Trav {
+    f3 mo, mu;                   /* ray in mesh space */
+    uint32_t node_base, tri_base;
+    uint32_t tri_cur, tri_end;   /* triangles of the current leaf still to test */
+    int top;                     /* stack pointer, -1 = empty */
+    int inst;                    /* instance being walked / next to scan */
+    int material;
+};
+
+template <bool STATS>
+__device__ __forceinline__ bool query_begin(const rt_dev_scene &S, f3 o, f3 d, float tmax, bool any_hit,
                                             Hit &h, Counters &cn)
 {
     h.type = HIT_NONE; h.id = 0; h.inst = 0; h.t = tmax; h.beta = 0.0f; h.gamma = 0.0f;
     h.material = -1; h.entered = false;
     cn.rays++;
-    if (STATS && SHADOW) cn.shadow_rays++;
+    if (STATS && any_hit) cn.shadow_rays++;
 
     for (int i = 0; i < S.light_count; i++) {
         const rt_dev_light &l = S.lights[i];
@@ -209,7 +235,7 @@ __device__ __forceinline__ void closest_hit(const rt_dev_scene &S, f3 o, f3 d, f
         if (STATS) cn.light_tests++;
         if (ball(ld3(l.c), l.radius, o, d, h.t, t, h.entered)) {
             h.type = HIT_LIGHT; h.id = (uint32_t)i; h.t = t;
-            if (SHADOW) return;
+            if (any_hit) return true;
         }
     }
     for (int i = 0; i < S.sphere_count; i++) {
@@ -218,7 +244,7 @@ __device__ __forceinline__ void closest_hit(const rt_dev_scene &S, f3 o, f3 d, f
         if (STATS) cn.sphere_tests++;
         if (ball(ld3(s.c), s.radius, o, d, h.t, t, h.entered)) {
             h.type = HIT_SPHERE; h.id = (uint32_t)i; h.t = t; h.material = s.material;
-            if (SHADOW) return;
+            if (any_hit) return true;
         }
     }
     for (int i = 0; i < S.plane_count; i++) {                        /* src/main.c:355-369 */
@@ -229,83 +255,125 @@ __device__ __forceinline__ void closest_hit(const rt_dev_scene &S, f3 o, f3 d, f
         if (t < 1e-3f) continue;
         if (t > h.t) continue;
         h.type = HIT_PLANE; h.id = (uint32_t)i; h.t = t; h.material = p.material;
-        if (SHADOW) return;
+        if (any_hit) return true;
     }
+    return S.instance_count == 0;
+}
 
-    for (int i = 0; i < S.instance_count; i++) {                     /* src/main.c:372-485 */
-        const rt_dev_instance &in = S.instances[i];
+/* from instance tv.inst on: true = tv is set up to walk an instance, false = no instance left */
+template <bool STATS>
+__device__ __forceinline__ bool query_scan(const rt_dev_scene &S, f3 o, f3 d, const Hit &h, Trav &tv,
+                                           Stack stk, Counters &cn)
+{
+    for (; tv.inst < S.instance_count; tv.inst++) {
+        const rt_dev_instance &in = S.instances[tv.inst];
         const rt_dev_mesh &m = S.meshes[in.mesh];
         /* ray into mesh space (src/math.c:299-311): row k = rotK . v */
         f3 rel = sub(o, ld3(in.pos));
         f3 rx = ld3(in.rx), ry = ld3(in.ry), rz = ld3(in.rz);
-        f3 mo = mk(rx.x * rel.x + rx.y * rel.y + rx.z * rel.z,
+        tv.mo = mk(rx.x * rel.x + rx.y * rel.y + rx.z * rel.z,
                    ry.x * rel.x + ry.y * rel.y + ry.z * rel.z,
                    rz.x * rel.x + rz.y * rel.y + rz.z * rel.z);
-        f3 mu = mk(rx.x * d.x + rx.y * d.y + rx.z * d.z,
+        tv.mu = mk(rx.x * d.x + rx.y * d.y + rx.z * d.z,
                    ry.x * d.x + ry.y * d.y + ry.z * d.z,
                    rz.x * d.x + rz.y * d.y + rz.z * d.z);
         if (STATS) cn.root_tests++;
-        {
-            float enter, leave;
-            slab(ld3(m.root_lo), ld3(m.root_hi), mo, mu, enter, leave);
-            if (leave < enter) continue;            /* equal passes: non-strict at the root */
-            if (enter > h.t) continue;
-        }
-        const rt_dev_node *nodes = S.nodes + m.node_base;
-        const rt_dev_tri *tris = S.tris + m.tri_base;
-        int top = 0;
+        float enter, leave;
+        slab(ld3(m.root_lo), ld3(m.root_hi), tv.mo, tv.mu, enter, leave);
+        if (leave < enter) continue;                /* equal passes: non-strict at the root */
+        if (enter > h.t) continue;
+        tv.node_base = m.node_base; tv.tri_base = m.tri_base; tv.material = in.material;
+        tv.top = 0; tv.tri_cur = 0; tv.tri_end = 0;
         stk.at(0) = m.root_entry;
-        while (top >= 0) {
-            uint32_t e = stk.at(top--);
-            if (!(e & RT_ENTRY_LEAF)) {
-                const rt_dev_node &nd = nodes[e];
-                const float4 *q = reinterpret_cast<const float4 *>(&nd);
-                float4 q0 = q[0], q1 = q[1], q2 = q[2];
-                uint4 q3 = *reinterpret_cast<const uint4 *>(q + 3);
-                if (q3.z & RT_NODE_PSEUDO) {         /* chunks of an oversized leaf, in order, no box test */
-                    stk.at(++top) = q3.y;
-                    stk.at(++top) = q3.x;
-                    continue;
-                }
-                if (STATS) cn.interior_pops++;
-                float e0, l0, e1, l1;
-                slab(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mo, mu, e0, l0);
-                slab(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), mo, mu, e1, l1);
-                bool h0 = (e0 < l0) && (e0 < h.t);   /* strict: a flat box is never entered */
-                bool h1 = (e1 < l1) && (e1 < h.t);
-                if (h0 && h1) {                      /* farther child first, nearer on top; ties: child 0 on top */
-                    bool swap = e0 > e1;
-                    stk.at(++top) = swap ? q3.x : q3.y;
-                    stk.at(++top) = swap ? q3.y : q3.x;
-                } else if (h0) stk.at(++top) = q3.x;
-                else if (h1) stk.at(++top) = q3.y;
-            } else {                                 /* src/main.c:449-482 */
-                if (STATS) cn.leaf_pops++;
-                uint32_t first = e & RT_ENTRY_FIRST_MASK;
-                uint32_t count = ((e >> RT_ENTRY_COUNT_SHIFT) & 15u) + 1u;
-                for (uint32_t j = first; j < first + count; j++) {
-                    if (STATS) cn.tri_tests++;
-                    const float4 *q = reinterpret_cast<const float4 *>(tris + j);
-                    float4 q0 = q[0], q1 = q[1], q2 = q[2];
-                    f3 a = mk(q0.x, q0.y, q0.z), e1v = mk(q0.w, q1.x, q1.y);
-                    f3 e2v = mk(q1.z, q1.w, q2.x), n = mk(q2.y, q2.z, q2.w);
-                    f3 oa = sub(mo, a);
-                    float den = dot(mu, n);
-                    float t = -dot(oa, n) / den;
-                    if (t < 1e-3f) continue;
-                    if (t > h.t) continue;
-                    f3 oau = cross(oa, mu);
-                    float beta = -dot(e2v, oau) / den;
-                    float gamma = dot(e1v, oau) / den;
-                    if ((beta < 0) || (beta > 1)) continue;
-                    if ((gamma < 0) || (gamma > 1)) continue;
-                    if (beta + gamma > 1) continue;
-                    h.type = HIT_TRIANGLE; h.t = t; h.id = j; h.inst = (uint32_t)i;
-                    h.beta = beta; h.gamma = gamma; h.material = in.material;
-                    if (SHADOW) return;
-                }
-            }
-        }
+        if (STATS) cn.tree_entries++;
+        return true;
+    }
+    return false;
+}
+
+enum : int { STEP_MORE = 0, STEP_INSTANCE_DONE = 1, STEP_QUERY_DONE = 2 };
+
+/* one triangle of the current leaf: src/main.c:449-482 (precondition tv.tri_cur < tv.tri_end) */
+template <bool STATS>
+__device__ __forceinline__ int query_tri_step(const rt_dev_scene &S, bool any_hit, Hit &h, Trav &tv, Counters &cn)
+{
+    const uint32_t j = tv.tri_cur++;
+    if (STATS) cn.tri_tests++;
+    const float4 *q = reinterpret_cast<const float4 *>(S.tris + tv.tri_base + j);
+    float4 q0 = q[0], q1 = q[1], q2 = q[2];
+    f3 a = mk(q0.x, q0.y, q0.z), e1v = mk(q0.w, q1.x, q1.y);
+    f3 e2v = mk(q1.z, q1.w, q2.x), n = mk(q2.y, q2.z, q2.w);
+    f3 oa = sub(tv.mo, a);
+    float den = dot(tv.mu, n);
+    float t = -dot(oa, n) / den;
+    if (t < 1e-3f) return STEP_MORE;
+    if (t > h.t) return STEP_MORE;
+    f3 oau = cross(oa, tv.mu);
+    float beta = -dot(e2v, oau) / den;
+    float gamma = dot(e1v, oau) / den;
+    if ((beta < 0) || (beta > 1)) return STEP_MORE;
+    if ((gamma < 0) || (gamma > 1)) return STEP_MORE;
+    if (beta + gamma > 1) return STEP_MORE;
+    h.type = HIT_TRIANGLE; h.t = t; h.id = j; h.inst = (uint32_t)tv.inst;
+    h.beta = beta; h.gamma = gamma; h.material = tv.material;
+    return any_hit ? STEP_QUERY_DONE : STEP_MORE;
+}
+
+/* one stack pop: src/main.c:397-447 (precondition: no triangle pending) */
+template <bool STATS>
+__device__ __forceinline__ int query_pop_step(const rt_dev_scene &S, Hit &h, Trav &tv, Stack stk, Counters &cn)
+{
+    if (tv.top < 0) { tv.inst++; return STEP_INSTANCE_DONE; }
+    const uint32_t e = stk.at(tv.top--);
+    if (e & RT_ENTRY_LEAF) {
+        if (STATS) cn.leaf_pops++;
+        tv.tri_cur = e & RT_ENTRY_FIRST_MASK;
+        tv.tri_end = tv.tri_cur + ((e >> RT_ENTRY_COUNT_SHIFT) & 15u) + 1u;
+        return STEP_MORE;
+    }
+    const float4 *q = reinterpret_cast<const float4 *>(S.nodes + tv.node_base + e);
+    float4 q0 = q[0], q1 = q[1], q2 = q[2];
+    uint4 q3 = *reinterpret_cast<const uint4 *>(q + 3);
+    if (q3.z & RT_NODE_PSEUDO) {                 /* chunks of an oversized leaf, in order, no box test */
+        stk.at(++tv.top) = q3.y;
+        stk.at(++tv.top) = q3.x;
+        return STEP_MORE;
+    }
+    if (STATS) cn.interior_pops++;
+    float e0, l0, e1, l1;
+    slab(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), tv.mo, tv.mu, e0, l0);
+    slab(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), tv.mo, tv.mu, e1, l1);
+    bool h0 = (e0 < l0) && (e0 < h.t);           /* strict: a flat box is never entered */
+    bool h1 = (e1 < l1) && (e1 < h.t);
+    if (h0 && h1) {                              /* farther child first, nearer on top; ties: child 0 on top */
+        bool swap = e0 > e1;
+        stk.at(++tv.top) = swap ? q3.x : q3.y;
+        stk.at(++tv.top) = swap ? q3.y : q3.x;
+    } else if (h0) stk.at(++tv.top) = q3.x;
+    else if (h1) stk.at(++tv.top) = q3.y;
+    return STEP_MORE;
+}
+
+template <bool STATS>
+__device__ __forceinline__ int query_step(const rt_dev_scene &S, bool any_hit, Hit &h, Trav &tv, Stack stk,
+                                          Counters &cn)
+{
+    if (tv.tri_cur < tv.tri_end) return query_tri_step<STATS>(S, any_hit, h, tv, cn);
+    return query_pop_step<STATS>(S, h, tv, stk, cn);
+}
+
+/* the whole query in one go (closest-hit probe kernel) */
+template <bool STATS>
+__device__ __forceinline__ void closest_hit(const rt_dev_scene &S, f3 o, f3 d, float tmax, bool any_hit,
+                                            Stack stk, Hit &h, Counters &cn)
+{
+    if (query_begin<STATS>(S, o, d, tmax, any_hit, h, cn)) return;
+    Trav tv;
+    tv.inst = 0;
+    while (query_scan<STATS>(S, o, d, h, tv, stk, cn)) {
+        int r;
+        do { r = query_step<STATS>(S, any_hit, h, tv, stk, cn); } while (r == STEP_MORE);
+        if (r == STEP_QUERY_DONE) return;
     }
 }
 
@@ -349,42 +417,6 @@ __device__ __forceinline__ f3 frame_tangent(f3 n)
     return unit(t);
 }
 
-/* next-event estimation, src/main.c:546-609 */
-template <class Rng, bool STATS>
-__device__ __forceinline__ void direct_light(const rt_dev_scene &S, Rng &rng, Stack stk, const Surface &sf,
-                                             f3 &sum, float &reached, Counters &cn)
-{
-    sum = mk(0, 0, 0);
-    reached = 0;
-    for (int i = 0; i < S.light_count; i++) {
-        const rt_dev_light &l = S.lights[i];
-        float r0, r1;
-        rng.uniform2(r0, r1);                          /* drawn before any early-out */
-        if (STATS) cn.rng_draws++;
-        float sn, cs;
-        rt_sincosf((float)(2 * RT_PI_D * (double)r0), &sn, &cs);
-        float ring = __builtin_sqrtf(2 * r1 - r1 * r1);
-        f3 hs = mk(cs * ring, sn * ring, 1 - r1);
-        f3 lc = ld3(l.c);
-        f3 axis = unit(sub(lc, sf.p));
-        f3 t0 = frame_tangent(axis);
-        f3 t1 = cross(axis, t0);
-        f3 q = add(scale(axis, -hs.z), add(scale(t0, -hs.y), scale(t1, -hs.x)));
-        q = scale(unit(q), l.radius);
-        f3 target = add(q, lc);
-        f3 path = sub(target, sf.p);
-        f3 dir = unit(path);
-        float cosine = dot(dir, sf.n);
-        if (cosine < 0) continue;
-        Hit blocker;
-        closest_hit<true, STATS>(S, sf.p, dir, len(path), stk, blocker, cn);
-        if (blocker.type != HIT_NONE) continue;
-        float power = (float)((double)l.albedo / (4.0 * RT_PI_D * (double)len2(path)));
-        sum = add(sum, scale(ld3(l.color), power * cosine));
-        reached += 1;
-    }
-}
-
 /* nearest texel, src/math.c:269-276 (double index arithmetic, truncation;
  * out-of-range coordinates, undefined for the host, are clamped) */
 __device__ __forceinline__ f3 texel(const rt_dev_scene &S, int texture, float u, float v)
@@ -398,101 +430,291 @@ __device__ __forceinline__ f3 texel(const rt_dev_scene &S, int texture, float u,
     return mk(px[0], px[1], px[2]);
 }
 
-/* one camera path, src/main.c:611-740 */
-template <class Rng, bool STATS>
-__device__ __forceinline__ f3 trace_path(const rt_dev_scene &S, Rng &rng, Stack stk, f3 o, f3 d,
-                                         int max_segments, Counters &cn)
-{
-    float lights_reached = 0;
-    f3 throughput = mk(1.0f, 1.0f, 1.0f);
-    f3 radiance = mk(0.0f, 0.0f, 0.0f);
-    bool inside_glass = false;
+/* ------------------------------------------------------------------ the path loop
+ *
+ * The host program nests its loops: samples > path segments > lights > tree
+ * nodes (src/main.c:762, 624, 550, 397).  A wave that executed them nested
+ * keeps most lanes idle: paths end at different segments, and a few lanes walk
+ * deep into a mesh tree while the rest wait (measured on the first kernel: 8
+ * of 64 lanes busy, 2-3 during tree walks).  Here every lane runs a flat loop
+ * with two kinds of step, and the WAVE decides by ballot which kind to run:
+ *
+ *   shade step  (lanes that are not inside a tree walk)
+ *       book the finished query: radiance, throughput, what comes next;
+ *       one "event" = ONE generator draw turned into a ray:
+ *          CAMERA  jittered primary ray                    (src/main.c:764-768)
+ *          NEE     shadow ray to a point on light `li`     (src/main.c:553-597)
+ *          BOUNCE  cosine-distributed continuation ray     (src/main.c:694-730)
+ *       (all three share draw, sincos(2 pi u0) and one square root; NEE and
+ *       BOUNCE share the tangent frame and the combination of the three axes);
+ *       lights / spheres / planes for the new ray, then the instance root boxes;
+ *   tree step   (lanes inside a tree walk)
+ *       one node pop or one triangle test.
+ *
+ * Lanes that need a tree walk are parked until enough of them have gathered
+ * (or nothing else is runnable); then the wave runs tree steps until enough
+ * lanes are ready to shade again.  Both kinds of step thus run with many
+ * lanes.  A lane executes, for its own path, exactly the operations the
+ * nested host loops execute, in the same order; only the interleaving between
+ * lanes differs, so results are unchanged.
+ */
+enum : int { EV_CAMERA = 0, EV_NEE = 1, EV_BOUNCE = 2, EV_TRACE_ONLY = 3 };
+enum : int { RAY_NONE = 0, RAY_SEGMENT = 1, RAY_SHADOW = 2 };
+enum : int { PH_SHADE = 0, PH_SCAN = 1, PH_TREE = 2, PH_DEAD = 3 };
 
-    for (int seg = 0; seg < max_segments; seg++) {
-        Hit h;
-        closest_hit<false, STATS>(S, o, d, 3.402823466e+38f, stk, h, cn);
-        if (h.type == HIT_NONE) break;
-        if (h.type == HIT_LIGHT) {
-            lights_reached += 1;
-            const rt_dev_light &l = S.lights[h.id];
-            float s = (float)((double)l.albedo / (4.0 * RT_PI_D * (double)h.t * (double)h.t));
-            radiance = add(radiance, mul(throughput, scale(ld3(l.color), s)));
-            break;
-        }
-        Surface sf;
-        surface_of<STATS>(S, o, d, h, sf, cn);
-        const rt_dev_material &m = S.materials[h.material];
-        if (m.kind == 1u) {                                   /* mirror, src/main.c:644-653 */
-            throughput = mul(throughput, ld3(m.mirror_color));
-            f3 along = scale(sf.n, dot(sf.n, d));
-            f3 across = sub(d, along);
-            o = sf.p;
-            d = sub(across, scale(along, 2.0f));              /* unnormalised on purpose */
-        } else if (m.kind == 2u) {                            /* glass, src/main.c:654-674 */
-            f3 along = scale(sf.n, dot(sf.n, d));
-            f3 across = sub(d, along);
-            float ratio = inside_glass ? m.ior : (1.0f / m.ior);
-            f3 bent = scale(across, ratio);
-            float b2 = len2(bent);
-            o = sf.p;
-            if (b2 > 1) {
-                d = sub(across, along);
+template <class Rng, bool STATS>
+struct PathMachine {
+    const rt_dev_scene &S;
+    Stack stk;
+    Counters &cn;
+    Rng rng;
+    float half_w, half_h;
+    int max_segments;
+
+    /* per-lane state */
+    int phase;                    /* PH_* */
+    int ev;                       /* next event */
+    int ray;                      /* kind of the query in flight / just finished */
+    uint32_t x, y;                /* pixel */
+    f3 o, d;                      /* current ray */
+    Hit h;                        /* its (partial) result */
+    Trav tv;
+    f3 throughput, radiance;
+    float lights_reached;
+    bool inside_glass;
+    int seg;
+    /* the diffuse vertex being lit */
+    f3 n, albedo, direct;
+    float reached_here, shadow_len2, shadow_cos;
+    int li;
+
+    __device__ __forceinline__ PathMachine(const rt_dev_scene &S_, Stack stk_, Counters &cn_)
+        : S(S_), stk(stk_), cn(cn_) {}
+
+    __device__ __forceinline__ void start_path()
+    {
+        throughput = mk(1.0f, 1.0f, 1.0f);
+        radiance = mk(0.0f, 0.0f, 0.0f);
+        lights_reached = 0;
+        inside_glass = false;
+        seg = 0;
+        ev = EV_CAMERA;
+        ray = RAY_NONE;
+        phase = PH_SHADE;
+    }
+
+    /* value of the finished path, src/main.c:735-739 and the clamp of 777-779 */
+    __device__ __forceinline__ f3 path_value() const
+    {
+        f3 c = mk(0.0f, 0.0f, 0.0f);
+        if (!(lights_reached == 0)) c = scale(radiance, 1 / lights_reached);
+        float c2 = len2(c);
+        if (c2 > 1e4f) c = scale(c, (float)(1e2 / (double)__builtin_sqrtf(c2)));
+        return c;
+    }
+
+    /* a segment was consumed: the host's loop counter (src/main.c:624) */
+    __device__ __forceinline__ bool segment_budget_left()
+    {
+        seg++;
+        return seg < max_segments;
+    }
+
+    /* after the last light of a diffuse vertex: src/main.c:677-692 */
+    __device__ __forceinline__ bool finish_vertex()
+    {
+        lights_reached += reached_here;
+        radiance = add(radiance, mul(throughput, mul(direct, albedo)));
+        throughput = mul(throughput, albedo);
+        if (len2(throughput) <= 9.99999997475242707878e-7f) return false;   /* < 1e-6 (double) on floats */
+        ev = EV_BOUNCE;
+        return true;
+    }
+
+    /* book the query that just finished; true = the path ended */
+    __device__ __forceinline__ bool book()
+    {
+        bool ended = false;
+        if (ray == RAY_SEGMENT) {
+            if (h.type == HIT_NONE) {
+                ended = true;
+            } else if (h.type == HIT_LIGHT) {                             /* src/main.c:631-643 */
+                lights_reached += 1;
+                const rt_dev_light &l = S.lights[h.id];
+                float s = (float)((double)l.albedo / (4.0 * RT_PI_D * (double)h.t * (double)h.t));
+                radiance = add(radiance, mul(throughput, scale(ld3(l.color), s)));
+                ended = true;
             } else {
-                inside_glass = !inside_glass;
-                f3 forward = scale(unit(along), __builtin_sqrtf(1 - b2));
-                d = add(forward, bent);
+                Surface sf;
+                surface_of<STATS>(S, o, d, h, sf, cn);
+                const rt_dev_material &m = S.materials[h.material];
+                if (m.kind == 1u) {                                       /* mirror, src/main.c:644-653 */
+                    throughput = mul(throughput, ld3(m.mirror_color));
+                    f3 along = scale(sf.n, dot(sf.n, d));
+                    f3 across = sub(d, along);
+                    o = sf.p;
+                    d = sub(across, scale(along, 2.0f));                  /* unnormalised on purpose */
+                    if (segment_budget_left()) ev = EV_TRACE_ONLY; else ended = true;
+                } else if (m.kind == 2u) {                                /* glass, src/main.c:654-674 */
+                    f3 along = scale(sf.n, dot(sf.n, d));
+                    f3 across = sub(d, along);
+                    float ratio = inside_glass ? m.ior : (1.0f / m.ior);
+                    f3 bent = scale(across, ratio);
+                    float b2 = len2(bent);
+                    o = sf.p;
+                    if (b2 > 1) {
+                        d = sub(across, along);
+                    } else {
+                        inside_glass = !inside_glass;
+                        f3 forward = scale(unit(along), __builtin_sqrtf(1 - b2));
+                        d = add(forward, bent);
+                    }
+                    if (segment_budget_left()) ev = EV_TRACE_ONLY; else ended = true;
+                } else {                                                  /* diffuse, src/main.c:675-683 */
+                    o = sf.p;
+                    n = sf.n;
+                    albedo = ld3(m.diffuse);
+                    if (m.texture >= 0) { albedo = texel(S, m.texture, sf.u, sf.v); if (STATS) cn.tex_lookups++; }
+                    direct = mk(0, 0, 0);
+                    reached_here = 0;
+                    li = 0;
+                    if (S.light_count > 0) ev = EV_NEE;
+                    else if (!finish_vertex()) ended = true;
+                }
             }
-        } else {                                              /* diffuse, src/main.c:675-732 */
-            f3 direct; float reached;
-            direct_light<Rng, STATS>(S, rng, stk, sf, direct, reached, cn);
-            lights_reached += reached;
-            f3 albedo = ld3(m.diffuse);
-            if (m.texture >= 0) { albedo = texel(S, m.texture, sf.u, sf.v); if (STATS) cn.tex_lookups++; }
-            radiance = add(radiance, mul(throughput, mul(direct, albedo)));
-            throughput = mul(throughput, albedo);
-            if (len2(throughput) <= 9.99999997475242707878e-7f) break;   /* < 1e-6 (double) on floats */
-            o = sf.p;
-            float r0, r1;
-            rng.uniform2(r0, r1);
-            if (STATS) cn.rng_draws++;
-            float sn, cs;
-            rt_sincosf((float)(2.0 * RT_PI_D * (double)r0), &sn, &cs);
-            float ring = __builtin_sqrtf(1 - r1);
-            f3 local = mk(cs * ring, sn * ring, __builtin_sqrtf(r1));
-            f3 t0 = frame_tangent(sf.n);
-            f3 t1 = cross(sf.n, t0);
-            f3 nd = add(scale(sf.n, local.z), add(scale(t0, -local.y), scale(t1, -local.x)));
-            nd = unit(nd);
-            throughput = scale(throughput, dot(nd, sf.n));
-            if (len2(throughput) <= 9.99999997475242707878e-7f) break;
-            d = nd;
+        } else if (ev == EV_NEE) {                                        /* a light sample came back (or was skipped) */
+            if (ray == RAY_SHADOW && h.type == HIT_NONE) {                /* src/main.c:599-605 */
+                const rt_dev_light &l = S.lights[li];
+                float power = (float)((double)l.albedo / (4.0 * RT_PI_D * (double)shadow_len2));
+                direct = add(direct, scale(ld3(l.color), power * shadow_cos));
+                reached_here += 1;
+            }
+            li++;
+            if (li >= S.light_count && !finish_vertex()) ended = true;
+        }
+        ray = RAY_NONE;
+        return ended;
+    }
+
+    /* one generator draw -> one ray (ray, o, d, tmax); true = the path ended instead */
+    __device__ __forceinline__ bool event(float &tmax)
+    {
+        tmax = 3.402823466e+38f;
+        if (ev == EV_TRACE_ONLY) { ray = RAY_SEGMENT; return false; }
+        bool ended = false;
+        float u0, u1;
+        rng.uniform2(u0, u1);
+        if (STATS) cn.rng_draws++;
+        float sn, cs;
+        rt_sincosf((float)(2.0 * RT_PI_D * (double)u0), &sn, &cs);
+        float arg;
+        if (ev == EV_CAMERA) arg = -2 * rt_logf(u1);                      /* Box-Muller radius^2, src/math.c:230 */
+        else if (ev == EV_NEE) arg = 2 * u1 - u1 * u1;                    /* src/main.c:555 */
+        else arg = 1 - u1;                                                /* src/main.c:696 */
+        float ring = __builtin_sqrtf(arg);
+        if (ev == EV_CAMERA) {
+            if (STATS) cn.samples++;
+            float jx = 0.0f + 0.25f * cs * ring;
+            float jy = 0.0f + 0.25f * sn * ring;
+            f3 dr = scale(ld3(S.cam.right), (float)x - half_w + 0.5f + jx);
+            f3 du = scale(ld3(S.cam.up), -((float)y - half_h + 0.5f + jy));
+            f3 dm = scale(ld3(S.cam.forward), S.cam.focal);
+            o = ld3(S.cam.pos);
+            d = unit(add(add(dr, du), dm));
+            ray = RAY_SEGMENT;
+        } else {
+            f3 axis, lc = mk(0, 0, 0);
+            float c0, c1 = -(sn * ring), c2 = -(cs * ring);
+            if (ev == EV_NEE) {
+                lc = ld3(S.lights[li].c);
+                axis = unit(sub(lc, o));                                  /* o is the vertex */
+                c0 = -(1 - u1);
+            } else {
+                axis = n;
+                c0 = __builtin_sqrtf(u1);
+            }
+            f3 t0 = frame_tangent(axis);
+            f3 t1 = cross(axis, t0);
+            f3 v = unit(add(scale(axis, c0), add(scale(t0, c1), scale(t1, c2))));
+            if (ev == EV_NEE) {
+                f3 q = scale(v, S.lights[li].radius);
+                f3 path = sub(add(q, lc), o);
+                f3 dir = unit(path);
+                shadow_cos = dot(dir, n);
+                if (!(shadow_cos < 0)) {
+                    d = dir;
+                    shadow_len2 = len2(path);
+                    tmax = __builtin_sqrtf(shadow_len2);
+                    ray = RAY_SHADOW;
+                }
+            } else {
+                throughput = scale(throughput, dot(v, n));
+                if (len2(throughput) <= 9.99999997475242707878e-7f) ended = true;
+                else {
+                    d = v;
+                    if (segment_budget_left()) ray = RAY_SEGMENT; else ended = true;
+                }
+            }
+        }
+        return ended;
+    }
+
+    /* shade step for the lanes in PH_SHADE / PH_SCAN.  on_end() is the caller's
+     * bookkeeping when a path ends (add path_value() to the pixel, start the
+     * next path or set phase = PH_DEAD). */
+    template <class OnEnd>
+    __device__ __forceinline__ void shade_step(OnEnd &&on_end)
+    {
+        if (phase == PH_SHADE) {
+            if (book()) on_end();
+            if (phase == PH_SHADE) {
+                float tmax;
+                if (event(tmax)) on_end();
+                else if (ray != RAY_NONE) {
+                    if (!query_begin<STATS>(S, o, d, tmax, ray == RAY_SHADOW, h, cn)) { tv.inst = 0; phase = PH_SCAN; }
+                }
+            }
+        }
+        if (phase == PH_SCAN)
+            phase = query_scan<STATS>(S, o, d, h, tv, stk, cn) ? PH_TREE : PH_SHADE;
+    }
+
+    __device__ __forceinline__ bool wants_shade() const { return phase == PH_SHADE || phase == PH_SCAN; }
+    __device__ __forceinline__ bool wants_tri() const { return phase == PH_TREE && tv.tri_cur < tv.tri_end; }
+    __device__ __forceinline__ bool wants_pop() const { return phase == PH_TREE && !(tv.tri_cur < tv.tri_end); }
+
+    __device__ __forceinline__ void after_tree(int r)
+    {
+        if (r == STEP_INSTANCE_DONE) phase = tv.inst < S.instance_count ? PH_SCAN : PH_SHADE;
+        else if (r == STEP_QUERY_DONE) phase = PH_SHADE;
+    }
+
+    /* the wave's scheduler: every lane wants exactly one kind of step (shade,
+     * pop a tree node, test a triangle); the wave runs the kind most lanes
+     * want, weighted (a shade step is long, so it should run fuller).  Runs
+     * until every lane is PH_DEAD. */
+    template <class OnEnd>
+    __device__ __forceinline__ void run(int shade_weight_q4, OnEnd &&on_end)
+    {
+        for (;;) {
+            const int n_shade = __popcll(__ballot(wants_shade()));
+            const int n_tri = __popcll(__ballot(wants_tri()));
+            const int n_pop = __popcll(__ballot(wants_pop()));
+            if (!(n_shade | n_tri | n_pop)) break;
+            const int s_shade = n_shade * shade_weight_q4;          /* weights in 1/16ths */
+            const int s_tri = n_tri * 16, s_pop = n_pop * 16;
+            if (s_shade >= s_tri && s_shade >= s_pop) {
+                if (STATS) { if ((threadIdx.x & 63) == 0) cn.shade_steps++; if (wants_shade()) cn.shade_lanes++; }
+                shade_step(on_end);
+            } else if (s_pop >= s_tri) {
+                if (STATS) { if ((threadIdx.x & 63) == 0) cn.pop_steps++; if (wants_pop()) cn.pop_lanes++; }
+                if (wants_pop()) after_tree(query_pop_step<STATS>(S, h, tv, stk, cn));
+            } else {
+                if (STATS) { if ((threadIdx.x & 63) == 0) cn.tri_steps++; if (wants_tri()) cn.tri_lanes++; }
+                if (wants_tri()) after_tree(query_tri_step<STATS>(S, ray == RAY_SHADOW, h, tv, cn));
+            }
         }
     }
-    if (lights_reached == 0) return mk(0.0f, 0.0f, 0.0f);
-    return scale(radiance, 1 / lights_reached);
-}
-
-/* one sample of pixel (x, y), src/main.c:764-779; half_w/half_h = size/2.0f */
-template <class Rng, bool STATS>
-__device__ __forceinline__ f3 sample_pixel(const rt_dev_scene &S, Rng &rng, Stack stk, uint32_t x, uint32_t y,
-                                           float half_w, float half_h, int max_segments, Counters &cn)
-{
-    float u0, u1;
-    rng.uniform2(u0, u1);
-    if (STATS) { cn.rng_draws++; cn.samples++; }
-    float sn, cs;
-    rt_sincosf((float)(2.0 * RT_PI_D * (double)u0), &sn, &cs);
-    float radius = __builtin_sqrtf(-2 * rt_logf(u1));
-    float jx = 0.0f + 0.25f * cs * radius;                    /* mean + sigma*cos*r, mean = 0 */
-    float jy = 0.0f + 0.25f * sn * radius;
-    f3 dr = scale(ld3(S.cam.right), (float)x - half_w + 0.5f + jx);
-    f3 du = scale(ld3(S.cam.up), -((float)y - half_h + 0.5f + jy));
-    f3 dm = scale(ld3(S.cam.forward), S.cam.focal);
-    f3 dir = unit(add(add(dr, du), dm));
-    f3 c = trace_path<Rng, STATS>(S, rng, stk, ld3(S.cam.pos), dir, max_segments, cn);
-    float c2 = len2(c);
-    if (c2 > 1e4f) c = scale(c, (float)(1e2 / (double)__builtin_sqrtf(c2)));    /* firefly clamp */
-    return c;
-}
+};
 
 } // namespace rt

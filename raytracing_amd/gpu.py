@@ -12,7 +12,7 @@ import numpy as np
 from . import scene_types as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_gpu.so")
+LIB_PATH = os.environ.get("RT_GPU_LIB", os.path.join(_HERE, "librt_gpu.so"))   # override: kernel-variant experiments
 
 FLAG_DETAILED_STATS = 1
 FLAG_ACCUMULATE = 2
@@ -41,7 +41,8 @@ class Options(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "samples", "rays", "shadow_rays", "root_tests", "interior_pops", "leaf_pops",
-        "tri_tests", "tri_hits", "tex_lookups", "rng_draws", "light_tests", "sphere_tests", "plane_tests")] + [
+        "tri_tests", "tri_hits", "tex_lookups", "rng_draws", "light_tests", "sphere_tests", "plane_tests",
+        "shade_steps", "pop_steps", "tri_steps", "shade_lanes", "pop_lanes", "tri_lanes", "tree_entries")] + [
         ("kernel_ms", C.c_double), ("launches", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
