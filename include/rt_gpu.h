@@ -78,8 +78,11 @@ typedef struct rt_gpu_stats {
     uint64_t shade_lanes, pop_lanes, tri_lanes;  /* ... and the lanes that took part in them (of 64 each) */
     uint64_t tree_entries;                       /* (ray, instance) pairs whose tree was entered          */
                              /* all but the first line only with RT_GPU_FLAG_DETAILED_STATS */
-    double   kernel_ms;      /* device time of the render kernels (HIP events) */
-    uint32_t launches;
+    double   kernel_ms;      /* device time of the shade + tree kernels (HIP events on their stream) */
+    double   shade_ms, tree_ms;  /* ... and each kernel's share */
+    uint64_t rounds;         /* shade launches (each but the last followed by a tree launch) */
+    uint64_t overflowed;     /* paths that found the parked list full and walked their tree in the shade kernel */
+    uint32_t launches;       /* render calls x sample batches */
     uint32_t reserved;
 } rt_gpu_stats;
 

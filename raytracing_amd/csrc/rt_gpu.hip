@@ -31,21 +31,10 @@
 /* kernels                                                                   */
 /* ------------------------------------------------------------------------ */
 
+/* which 8x8 pixel blocks ("units") of a region one launch covers */
 struct RenderParams {
-    rt_dev_scene S;
-    float   *pixels;
-    uint64_t *stats;
-    uint32_t width, height;          /* image */
-    uint32_t x0, y0, w, h;           /* region */
-    uint32_t blocks_x, block_rows;   /* 8x8 pixel blocks this launch walks */
+    uint32_t blocks_x, block_rows;
     uint32_t band_blocks, band_rank, band_count;   /* 0 band_blocks = no split */
-    float   *samples;                /* scratch: [sample of this launch][wave][pixel of the 8x8 block] RGB */
-    uint32_t first_sample, launch_spp;   /* this launch renders samples first_sample .. +launch_spp of the call */
-    uint32_t spp, sample_offset, seed0, seed1;
-    int      max_segments;
-    uint32_t accumulate;
-    int      shade_weight;           /* scheduler weight, see rt::PathMachine::run */
-    float    norm, half_w, half_h;
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -73,65 +62,271 @@ __device__ __forceinline__ void flush_counters(const rt::Counters &cn, uint64_t 
     }
 }
 
-/* One wave = one 8x8 pixel block and ALL its (pixel, sample) work items of this
- * launch; lanes take items from a wave-local counter as they become free, so no
- * lane waits for a neighbour whose pixel needs longer paths.  Sample values go
- * to a scratch buffer; rt_resolve_kernel adds them up per pixel in sample order
- * (the host's per-pixel sum is a sequential float sum, src/main.c:785). */
-template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
-rt_render_pixels_kernel(const RenderParams P)
+/* ------------------------------------------------------------------------
+ * The frame is rendered by two kernels that hand paths to each other through
+ * HBM:
+ *
+ *   rt_shade_kernel   everything of the path loop except walking mesh trees.
+ *       A lane carries a path through events (draw -> ray -> lights, spheres,
+ *       planes, instance root boxes -> bookkeeping) until the path ends (its
+ *       value goes to the sample scratch) or its ray enters an instance's root
+ *       box; then the lane writes the path as a 192-byte record to the parked
+ *       list and takes the next path: it never waits for a tree walk.
+ *   rt_tree_kernel    walks the trees for the parked rays only (6 % of the
+ *       rays of the benchmark frame, ~40 node/triangle steps each): small
+ *       register footprint, many waves per SIMD to hide the dependent fetches,
+ *       lanes take the next parked ray as soon as theirs is done.
+ *
+ * Round 0 shades fresh (pixel, sample) items; round r > 0 resumes the paths
+ * parked in round r-1 after the tree kernel has answered their queries.  The
+ * loop ends when a shade launch parks nothing.  A path executes exactly the
+ * operations of the host's nested loops in the same order whatever lane or
+ * launch runs them, so results do not change.
+ * ------------------------------------------------------------------------ */
+#define RT_CHUNK 256u                /* parked-list slots a wave reserves per atomic */
+
+struct QueueCounters {               /* device words, zeroed per launch where noted */
+    uint32_t unit_next;              /* fresh: next 8x8 pixel block */
+    uint32_t in_next;                /* resume / tree: next slot of the input list */
+    uint32_t out_reserved;           /* shade: slots reserved in the output list */
+    uint32_t overflow;               /* shade: paths that found the output list full (finished in place) */
+};
+
+struct ShadeParams {
+    rt_dev_scene S;
+    float   *samples;                /* [sample of this launch][unit][pixel of the 8x8 block] RGB */
+    uint64_t *stats;
+    QueueCounters *q;
+    const uint32_t *in_list;         /* resume: records parked by the previous round (answered) */
+    uint32_t *out_list;              /* records this launch parks */
+    uint32_t in_slots, out_capacity;
+    uint32_t width, height;          /* image */
+    uint32_t x0, y0, w, h;           /* region */
+    uint32_t blocks_x, block_rows;   /* units = 8x8 pixel blocks of this launch */
+    uint32_t band_blocks, band_rank, band_count;
+    uint32_t first_sample, launch_spp, sample_offset, seed0, seed1;
+    int      max_segments;
+    float    half_w, half_h;
+};
+
+template <bool FRESH, bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK)
+rt_shade_kernel(const ShadeParams P)
 {
     extern __shared__ uint32_t lds[];
-    rt::Stack stk; stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK;
-    uint32_t *next_item = lds + RT_BLOCK * P.S.stack_cap + (threadIdx.x >> 6);   /* one word per wave */
+    rt::Stack stk; stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK;     /* used only on list overflow */
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
-
-    const uint32_t wave = (blockIdx.x * RT_BLOCK + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
-    const bool wave_live = wave < P.blocks_x * P.block_rows;
-    uint32_t bx = 0, by = 0;
-    if (wave_live) {
-        bx = wave % P.blocks_x;
-        by = wave / P.blocks_x;
-        if (P.band_blocks) {
-            uint32_t k = by / P.band_blocks, in = by % P.band_blocks;
-            by = (k * P.band_count + P.band_rank) * P.band_blocks + in;
-        }
-    }
-    if (lane == 0) *next_item = 0;
-    const uint32_t items = wave_live ? 64u * P.launch_spp : 0u;
-    float *my_samples = P.samples + 3 * (size_t)wave * 64;
-    const size_t sample_stride = 3 * (size_t)P.blocks_x * P.block_rows * 64;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
     rt::PathMachine<rt::CounterRng, STATS> pm(P.S, stk, cn);
     pm.half_w = P.half_w; pm.half_h = P.half_h; pm.max_segments = P.max_segments;
     pm.rng.seed0 = P.seed0; pm.rng.seed1 = P.seed1;
-    uint32_t item = 0;
+    pm.phase = rt::PH_DEAD;
+    bool has = false;
+    uint32_t sample_index = 0;
 
-    /* next work item of this wave for this lane: item k = pixel k%64 of the block, sample k/64 */
-    auto take_item = [&]() {
-        for (;;) {
-            item = atomicAdd(next_item, 1u);
-            if (item >= items) { pm.phase = rt::PH_DEAD; return; }
-            const uint32_t p = item & 63u;
-            const uint32_t lx = bx * 8 + (p & 7), ly = by * 8 + (p >> 3);
-            if (lx < P.w && ly < P.h) {
-                pm.x = P.x0 + lx; pm.y = P.y0 + ly;
-                pm.start_path();
-                pm.rng.begin(P.width * pm.y + pm.x, P.sample_offset + P.first_sample + (item >> 6));
-                return;
+    /* wave-uniform cursors */
+    const uint32_t units = P.blocks_x * P.block_rows;
+    const uint32_t unit_items = 64u * P.launch_spp;
+    uint32_t unit = 0, item_next = unit_items;          /* fresh: current unit and next item in it */
+    uint32_t bx = 0, by = 0;
+    uint32_t in_cur = 0, in_end = 0;                    /* resume: reserved input range */
+    bool input_done = false;
+    uint32_t out_cur = 0, out_end = 0;                  /* reserved output range */
+
+    for (;;) {
+        /* ---- 1. give free lanes a path ----------------------------------------- */
+        while (!input_done) {
+            const unsigned long long need = __ballot(!has);
+            if (!need) break;
+            if (FRESH) {
+                if (item_next >= unit_items) {           /* next 8x8 block */
+                    uint32_t u = 0;
+                    if (lane == 0) u = atomicAdd(&P.q->unit_next, 1u);
+                    unit = __builtin_amdgcn_readfirstlane(u);
+                    if (unit >= units) { input_done = true; break; }
+                    item_next = 0;
+                    bx = unit % P.blocks_x; by = unit / P.blocks_x;
+                    if (P.band_blocks) {
+                        uint32_t k = by / P.band_blocks, in = by % P.band_blocks;
+                        by = (k * P.band_count + P.band_rank) * P.band_blocks + in;
+                    }
+                }
+                const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
+                const uint32_t item = item_next + rank;
+                if (!has && item < unit_items) {
+                    const uint32_t p = item & 63u;
+                    const uint32_t lx = bx * 8 + (p & 7), ly = by * 8 + (p >> 3);
+                    if (lx < P.w && ly < P.h) {
+                        pm.x = P.x0 + lx; pm.y = P.y0 + ly;
+                        pm.start_path();
+                        pm.rng.begin(P.width * pm.y + pm.x, P.sample_offset + P.first_sample + (item >> 6));
+                        sample_index = ((item >> 6) * units + unit) * 64u + p;
+                        has = true;
+                    }
+                }
+                item_next += (uint32_t)__popcll(need);
+                if (item_next > unit_items) item_next = unit_items;
+            } else {
+                if (in_cur >= in_end) {                  /* next 64 slots of the parked list */
+                    uint32_t v = 0;
+                    if (lane == 0) v = atomicAdd(&P.q->in_next, 64u);
+                    in_cur = __builtin_amdgcn_readfirstlane(v);
+                    if (in_cur >= P.in_slots) { input_done = true; break; }
+                    in_end = in_cur + 64u < P.in_slots ? in_cur + 64u : P.in_slots;
+                }
+                const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
+                const uint32_t idx = in_cur + rank;
+                if (!has && idx < in_end)
+                    has = pm.load_record(P.in_list + (size_t)idx * RT_RECORD_WORDS, sample_index);
+                in_cur += (uint32_t)__popcll(need);
+                if (in_cur > in_end) in_cur = in_end;
             }
+            if (__ballot(has) == ~0ull) break;
         }
-    };
-    take_item();
+        if (!__ballot(has)) break;                       /* nothing in flight and no input left */
 
-    pm.run(P.shade_weight, [&]() {
-        const rt::f3 c = pm.path_value();
-        float *dst = my_samples + (size_t)(item >> 6) * sample_stride + 3 * (item & 63u);
-        dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
-        take_item();
-    });
+        /* ---- 2. one shade step ---------------------------------------------------- */
+        if (has) {
+            pm.shade_step_park([&]() {
+                const rt::f3 c = pm.path_value();
+                float *dst = P.samples + 3 * (size_t)sample_index;
+                dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
+                has = false;
+                pm.phase = rt::PH_DEAD;
+            });
+        }
+
+        /* ---- 3. park the lanes whose ray has to walk a tree ------------------------- */
+        const unsigned long long parking = __ballot(has && pm.phase == rt::PH_PARK);
+        if (parking) {
+            const uint32_t count = (uint32_t)__popcll(parking);
+            const uint32_t rank = (uint32_t)__popcll(parking & lanes_below);
+            const uint32_t room = out_end - out_cur;
+            uint32_t next_base = 0;
+            if (count > room) {                          /* reserve the next chunk; the old one is filled to its end */
+                uint32_t v = 0;
+                if (lane == 0) v = atomicAdd(&P.q->out_reserved, RT_CHUNK);
+                next_base = __builtin_amdgcn_readfirstlane(v);
+            }
+            if (has && pm.phase == rt::PH_PARK) {
+                uint32_t slot = rank < room ? out_cur + rank : next_base + (rank - room);
+                if (slot < P.out_capacity) {
+                    pm.store_record(P.out_list + (size_t)slot * RT_RECORD_WORDS, sample_index);
+                    has = false;
+                    pm.phase = rt::PH_DEAD;
+                } else {                                  /* list full: walk the tree right here (slow, still exact) */
+                    atomicAdd(&P.q->overflow, 1u);
+                    pm.tv.inst = pm.park_inst;
+                    while (rt::query_scan<STATS>(P.S, pm.o, pm.d, pm.h, pm.tv, stk, cn)) {
+                        int r;
+                        do { r = rt::query_step<STATS>(P.S, pm.ray == rt::RAY_SHADOW, pm.h, pm.tv, stk, cn); }
+                        while (r == rt::STEP_MORE);
+                        if (r == rt::STEP_QUERY_DONE) break;
+                    }
+                    pm.phase = rt::PH_SHADE;
+                }
+            }
+            if (count > room) { out_cur = next_base + (count - room); out_end = next_base + RT_CHUNK; }
+            else out_cur += count;
+        }
+    }
+    /* unused tail of the last reserved chunk: mark the slots empty */
+    for (uint32_t slot = out_cur + lane; slot < out_end && slot < P.out_capacity; slot += 64)
+        P.out_list[(size_t)slot * RT_RECORD_WORDS] = 0u;
+    flush_counters<STATS>(cn, P.stats);
+}
+
+struct TreeParams {
+    rt_dev_scene S;
+    uint32_t *list;                  /* parked records: word 0..15 read, 8..14 written back */
+    uint32_t slots;
+    QueueCounters *q;
+    uint64_t *stats;
+};
+
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK)
+rt_tree_kernel(const TreeParams P)
+{
+    extern __shared__ uint32_t lds[];
+    rt::Stack stk; stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK;
+    rt::Counters cn; memset(&cn, 0, sizeof(cn));
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+    bool busy = false, any_hit = false;
+    uint32_t slot = 0;
+    rt::f3 o = rt::mk(0, 0, 0), d = rt::mk(0, 0, 0);
+    rt::Hit h; h.type = rt::HIT_NONE; h.id = 0; h.inst = 0; h.t = 0; h.beta = 0; h.gamma = 0; h.material = -1; h.entered = false;
+    rt::Trav tv; memset(&tv, 0, sizeof(tv)); tv.top = -1;
+    uint32_t w15 = 0;
+    uint32_t in_cur = 0, in_end = 0;
+    bool input_done = false;
+
+    auto finish = [&]() {                                /* answer the query: write the hit back */
+        uint4 *q = reinterpret_cast<uint4 *>(P.list + (size_t)slot * RT_RECORD_WORDS);
+        q[2] = make_uint4(__float_as_uint(h.t), (uint32_t)h.type, h.id, h.inst);
+        q[3] = make_uint4(__float_as_uint(h.beta), __float_as_uint(h.gamma), (uint32_t)h.material, w15);
+        busy = false;
+    };
+
+    for (;;) {
+        /* ---- free lanes take the next parked rays ---------------------------------- */
+        while (!input_done) {
+            const unsigned long long need = __ballot(!busy);
+            if (!need) break;
+            if (in_cur >= in_end) {
+                uint32_t v = 0;
+                if (lane == 0) v = atomicAdd(&P.q->in_next, 64u);
+                in_cur = __builtin_amdgcn_readfirstlane(v);
+                if (in_cur >= P.slots) { input_done = true; break; }
+                in_end = in_cur + 64u < P.slots ? in_cur + 64u : P.slots;
+            }
+            const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
+            const uint32_t idx = in_cur + rank;
+            if (!busy && idx < in_end) {
+                const uint4 *q = reinterpret_cast<const uint4 *>(P.list + (size_t)idx * RT_RECORD_WORDS);
+                const uint4 a = q[0];
+                if (a.x & 1u) {
+                    const uint4 b = q[1], c = q[2], e = q[3];
+                    slot = idx;
+                    any_hit = ((a.x >> 3) & 3u) == (uint32_t)rt::RAY_SHADOW;
+                    o = rt::mk(__uint_as_float(a.z), __uint_as_float(a.w), __uint_as_float(b.x));
+                    d = rt::mk(__uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+                    h.t = __uint_as_float(c.x); h.type = (int)c.y; h.id = c.z; h.inst = c.w;
+                    h.beta = __uint_as_float(e.x); h.gamma = __uint_as_float(e.y); h.material = (int)e.z;
+                    w15 = e.w;
+                    tv.inst = (int)(e.w & 0xFFFFu);
+                    busy = true;
+                    if (STATS) cn.root_tests--;          /* the shade kernel already counted this root test */
+                    if (!rt::query_scan<STATS>(P.S, o, d, h, tv, stk, cn)) finish();
+                }
+            }
+            in_cur += (uint32_t)__popcll(need);
+            if (in_cur > in_end) in_cur = in_end;
+            if (__ballot(busy) == ~0ull) break;
+        }
+        const unsigned long long working = __ballot(busy);
+        if (!working) break;
+
+        /* ---- one tree step of the kind most working lanes want ------------------------ */
+        const bool want_tri = busy && tv.tri_cur < tv.tri_end;
+        const int n_tri = __popcll(__ballot(want_tri)), n_pop = __popcll(working) - n_tri;
+        int r = rt::STEP_MORE;
+        if (n_tri >= n_pop) {
+            if (STATS) { if (lane == 0) cn.tri_steps++; if (want_tri) cn.tri_lanes++; }
+            if (want_tri) r = rt::query_tri_step<STATS>(P.S, any_hit, h, tv, cn);
+        } else {
+            if (STATS) { if (lane == 0) cn.pop_steps++; if (busy && !want_tri) cn.pop_lanes++; }
+            if (busy && !want_tri) r = rt::query_pop_step<STATS>(P.S, h, tv, stk, cn);
+        }
+        if (r == rt::STEP_QUERY_DONE) finish();
+        else if (r == rt::STEP_INSTANCE_DONE) {
+            if (!(tv.inst < P.S.instance_count) || !rt::query_scan<STATS>(P.S, o, d, h, tv, stk, cn)) finish();
+        }
+    }
     flush_counters<STATS>(cn, P.stats);
 }
 
@@ -320,7 +515,13 @@ struct rt_gpu_scene {
     uint64_t *d_stats = nullptr;
     uint32_t *d_aes_table = nullptr;
     float *d_frame = nullptr; size_t frame_floats = 0;
-    float *d_samples = nullptr; uint64_t scratch_bytes = 0;   /* per-sample values between trace and resolve */
+    float *d_samples = nullptr; uint64_t scratch_bytes = 0;   /* per-sample values between shading and resolve */
+    uint32_t *d_parked[2] = {nullptr, nullptr}; uint64_t parked_records = 0;   /* paths in transit, ping-pong */
+    QueueCounters *d_queue = nullptr;
+    uint32_t shade_blocks = 0, tree_blocks = 0;               /* persistent grid sizes */
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tree_timers;
+    double tree_ms = 0.0;
+    uint64_t overflowed = 0, rounds = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timers;   /* pending kernel timings */
     std::vector<hipEvent_t> spare_events;
     double kernel_ms = 0.0;
@@ -386,6 +587,8 @@ void rt_gpu_scene_destroy(rt_gpu_scene *s)
     for (void *p : s->allocations) (void)hipFree(p);
     if (s->d_frame) (void)hipFree(s->d_frame);
     if (s->d_samples) (void)hipFree(s->d_samples);
+    for (int k = 0; k < 2; k++) if (s->d_parked[k]) (void)hipFree(s->d_parked[k]);
+    for (auto &t : s->tree_timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     for (auto &t : s->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     for (auto e : s->spare_events) (void)hipEventDestroy(e);
     delete s;
@@ -435,6 +638,18 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
         const uint64_t *st = nullptr;
         if ((rc = upload(s, zeros, &st))) break;
         s->d_stats = const_cast<uint64_t *>(st);
+        std::vector<uint32_t> qzero(sizeof(QueueCounters) / 4, 0);
+        const uint32_t *qp = nullptr;
+        if ((rc = upload(s, qzero, &qp))) break;
+        s->d_queue = reinterpret_cast<QueueCounters *>(const_cast<uint32_t *>(qp));
+        {   /* persistent grids: as many workgroups as the device keeps resident */
+            const size_t lds_bytes = (size_t)RT_BLOCK * flat.stack_cap * 4;
+            int per_cu_shade = 0, per_cu_tree = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, rt_shade_kernel<true, false>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_shade < 1) per_cu_shade = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tree, rt_tree_kernel<false>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_tree < 1) per_cu_tree = 1;
+            s->shade_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_shade);
+            s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
+        }
         std::vector<uint32_t> table(256);
         build_aes_table(table.data());
         const uint32_t *tb = nullptr;
@@ -455,13 +670,25 @@ int rt_gpu_scene_set_camera(rt_gpu_scene *s, const void *camera)
     return RT_GPU_OK;
 }
 
-static int ensure_scratch(rt_gpu_scene *s, uint64_t bytes)
+static int ensure_scratch(rt_gpu_scene *s, uint64_t sample_bytes, uint64_t parked_records)
 {
-    if (s->scratch_bytes >= bytes) return 0;
-    if (s->d_samples) { (void)hipDeviceSynchronize(); (void)hipFree(s->d_samples); s->d_samples = nullptr; s->scratch_bytes = 0; }
-    if (hipMalloc(reinterpret_cast<void **>(&s->d_samples), bytes) != hipSuccess)
-        return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the sample scratch (" + std::to_string(bytes >> 20) + " MiB)");
-    s->scratch_bytes = bytes;
+    if (s->scratch_bytes < sample_bytes) {
+        if (s->d_samples) { (void)hipDeviceSynchronize(); (void)hipFree(s->d_samples); s->d_samples = nullptr; s->scratch_bytes = 0; }
+        if (hipMalloc(reinterpret_cast<void **>(&s->d_samples), sample_bytes) != hipSuccess)
+            return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the sample scratch (" + std::to_string(sample_bytes >> 20) + " MiB)");
+        s->scratch_bytes = sample_bytes;
+    }
+    if (s->parked_records < parked_records) {
+        (void)hipDeviceSynchronize();
+        for (int k = 0; k < 2; k++) {
+            if (s->d_parked[k]) { (void)hipFree(s->d_parked[k]); s->d_parked[k] = nullptr; }
+            if (hipMalloc(reinterpret_cast<void **>(&s->d_parked[k]), parked_records * RT_RECORD_WORDS * 4) != hipSuccess) {
+                s->parked_records = 0;
+                return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the parked-path lists");
+            }
+        }
+        s->parked_records = parked_records;
+    }
     return 0;
 }
 
@@ -483,6 +710,14 @@ static void settle_timers(rt_gpu_scene *s)
         s->spare_events.push_back(t.second);
     }
     s->timers.clear();
+    for (auto &t : s->tree_timers) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(t.second) == hipSuccess && hipEventElapsedTime(&ms, t.first, t.second) == hipSuccess)
+            s->tree_ms += ms;
+        s->spare_events.push_back(t.first);
+        s->spare_events.push_back(t.second);
+    }
+    s->tree_timers.clear();
 }
 
 /* which 8-row block rows of the region this launch walks; *own_rows = pixel rows among them */
@@ -527,69 +762,115 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     RT_HIP(hipSetDevice(s->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
 
-    RenderParams P;
-    memset(&P, 0, sizeof(P));
+    RenderParams G;
+    memset(&G, 0, sizeof(G));
     uint32_t own_rows = 0;
-    int rc = launch_geometry(o, region, P, &own_rows);
+    int rc = launch_geometry(o, region, G, &own_rows);
     if (rc) return rc;
+    if (G.block_rows == 0) return RT_GPU_OK;
+    if (width > 0xFFFFu || height > 0xFFFFu) return fail(RT_GPU_ERR_ARGUMENT, "image sides above 65535 are not supported");
     const uint32_t flags = o ? o->flags : 0;
+    const bool detailed = (flags & RT_GPU_FLAG_DETAILED_STATS) != 0;
+    const bool accumulate = (flags & RT_GPU_FLAG_ACCUMULATE) != 0;
+
+    ShadeParams P;
+    memset(&P, 0, sizeof(P));
     P.S = s->dev;
     P.S.cam.focal = rt_camera_focal(s->field_of_view, height);
     P.stats = s->d_stats;
+    P.q = s->d_queue;
     P.width = width; P.height = height;
     P.x0 = region.point.x; P.y0 = region.point.y; P.w = region.size.x; P.h = region.size.y;
+    P.blocks_x = G.blocks_x; P.block_rows = G.block_rows;
+    P.band_blocks = G.band_blocks; P.band_rank = G.band_rank; P.band_count = G.band_count;
     P.sample_offset = o ? o->sample_offset : 0;
     P.seed0 = (uint32_t)seed; P.seed1 = (uint32_t)(seed >> 32);
     P.max_segments = (o && o->max_segments) ? (int)o->max_segments : 64;
     P.half_w = (float)width / 2.0f; P.half_h = (float)height / 2.0f;
-    P.shade_weight = RT_SHADE_WEIGHT;
-    if (const char *e = getenv("RT_GPU_SHADE_WEIGHT")) P.shade_weight = atoi(e);   /* tuning aid */
-    if (P.block_rows == 0) return RT_GPU_OK;
 
     ResolveParams R;
     memset(&R, 0, sizeof(R));
     R.pixels = device_pixels;
     R.x0 = P.x0; R.y0 = P.y0; R.w = P.w; R.h = P.h;
-    R.blocks_x = P.blocks_x; R.block_rows = P.block_rows;
-    R.band_blocks = P.band_blocks; R.band_rank = P.band_rank; R.band_count = P.band_count;
+    R.blocks_x = G.blocks_x; R.block_rows = G.block_rows;
+    R.band_blocks = G.band_blocks; R.band_rank = G.band_rank; R.band_count = G.band_count;
     R.compact = (flags & RT_GPU_FLAG_COMPACT_BANDS) ? 1 : 0;
     R.out_pitch = R.compact ? region.size.x : width;
     R.norm = rt_pixel_norm((o && o->spp_total) ? o->spp_total : spp);
-    const bool accumulate = (flags & RT_GPU_FLAG_ACCUMULATE) != 0;
 
-    /* sample scratch: 12 bytes per (pixel slot, sample); a call is cut into launches that fit the budget */
-    const uint64_t waves = (uint64_t)P.blocks_x * P.block_rows;
-    const uint64_t bytes_per_sample = waves * 64 * 12;
-    uint64_t budget = (uint64_t)4096 << 20;
-    if (const char *e = getenv("RT_GPU_SCRATCH_MB")) budget = (uint64_t)atoll(e) << 20;
-    uint64_t per_launch = budget / bytes_per_sample;
+    /* how many samples per pixel one launch carries: bounded by the sample scratch (12 bytes per
+     * item) and by the parked lists (2 x 192 bytes per item that can be in flight) */
+    const uint64_t units = (uint64_t)G.blocks_x * G.block_rows;
+    const uint64_t items_per_sample = units * 64;
+    uint64_t scratch_mb = 4096, parked_mb = 12288;
+    if (const char *e = getenv("RT_GPU_SCRATCH_MB")) scratch_mb = (uint64_t)atoll(e);
+    if (const char *e = getenv("RT_GPU_PARKED_MB")) parked_mb = (uint64_t)atoll(e);
+    uint64_t per_launch = (scratch_mb << 20) / (items_per_sample * 12);
     if (per_launch < 1) per_launch = 1;
     if (per_launch > spp) per_launch = spp;
-    rc = ensure_scratch(s, per_launch * bytes_per_sample);
+    if (per_launch * items_per_sample > 0xFFFFFF00ull / 3) per_launch = (0xFFFFFF00ull / 3) / items_per_sample;
+    if (per_launch < 1) return fail(RT_GPU_ERR_ARGUMENT, "region too large for one launch");
+    uint64_t capacity = ((parked_mb << 20) / 2) / (RT_RECORD_WORDS * 4);       /* records per list */
+    if (capacity > per_launch * items_per_sample) capacity = per_launch * items_per_sample;
+    capacity = (capacity + RT_CHUNK - 1) / RT_CHUNK * RT_CHUNK;
+    if (capacity > 0xFFFFFF00ull) capacity = 0xFFFFFF00ull / RT_CHUNK * RT_CHUNK;
+    rc = ensure_scratch(s, per_launch * items_per_sample * 12, capacity);
     if (rc) return rc;
     P.samples = s->d_samples; R.samples = s->d_samples;
+    P.out_capacity = (uint32_t)capacity;
 
-    const uint32_t grid = (uint32_t)((waves * 64 + RT_BLOCK - 1) / RT_BLOCK);
-    const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4 + 4 * (RT_BLOCK / 64);
+    const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
+    const uint32_t shade_grid = s->shade_blocks, tree_grid = s->tree_blocks;
+    const uint32_t resolve_grid = (uint32_t)((units * 64 + RT_BLOCK - 1) / RT_BLOCK);
+
     for (uint32_t first = 0; first < spp; first += (uint32_t)per_launch) {
         P.first_sample = first;
         P.launch_spp = (uint32_t)(spp - first < per_launch ? spp - first : per_launch);
-        hipEvent_t e0 = take_event(s), e1 = take_event(s);
-        if (e0 && e1) RT_HIP(hipEventRecord(e0, stream));
-        if (flags & RT_GPU_FLAG_DETAILED_STATS)
-            hipLaunchKernelGGL(rt_render_pixels_kernel<true>, dim3(grid), dim3(RT_BLOCK), lds, stream, P);
-        else
-            hipLaunchKernelGGL(rt_render_pixels_kernel<false>, dim3(grid), dim3(RT_BLOCK), lds, stream, P);
-        RT_HIP(hipGetLastError());
-        if (e0 && e1) { RT_HIP(hipEventRecord(e1, stream)); s->timers.emplace_back(e0, e1); }
+        uint32_t *list_in = s->d_parked[0], *list_out = s->d_parked[1];
+        uint32_t in_slots = 0;
+        for (uint32_t round = 0;; round++) {
+            RT_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(QueueCounters), stream));
+            P.in_list = list_in; P.in_slots = in_slots; P.out_list = list_out;
+            hipEvent_t e0 = take_event(s), e1 = take_event(s);
+            if (e0 && e1) RT_HIP(hipEventRecord(e0, stream));
+            if (round == 0) {
+                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<true, true>), dim3(shade_grid), dim3(RT_BLOCK), lds, stream, P);
+                else hipLaunchKernelGGL((rt_shade_kernel<true, false>), dim3(shade_grid), dim3(RT_BLOCK), lds, stream, P);
+            } else {
+                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<false, true>), dim3(shade_grid), dim3(RT_BLOCK), lds, stream, P);
+                else hipLaunchKernelGGL((rt_shade_kernel<false, false>), dim3(shade_grid), dim3(RT_BLOCK), lds, stream, P);
+            }
+            RT_HIP(hipGetLastError());
+            if (e0 && e1) { RT_HIP(hipEventRecord(e1, stream)); s->timers.emplace_back(e0, e1); }
+            QueueCounters qc;
+            RT_HIP(hipMemcpyAsync(&qc, s->d_queue, sizeof(qc), hipMemcpyDeviceToHost, stream));
+            RT_HIP(hipStreamSynchronize(stream));
+            s->overflowed += qc.overflow;
+            s->rounds++;
+            uint32_t parked = qc.out_reserved < capacity ? qc.out_reserved : (uint32_t)capacity;
+            if (parked == 0) break;
+            /* answer the parked queries, then resume those paths */
+            TreeParams T;
+            memset(&T, 0, sizeof(T));
+            T.S = P.S; T.list = list_out; T.slots = parked; T.q = s->d_queue; T.stats = s->d_stats;
+            RT_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(QueueCounters), stream));
+            hipEvent_t t0 = take_event(s), t1 = take_event(s);
+            if (t0 && t1) RT_HIP(hipEventRecord(t0, stream));
+            if (detailed) hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(tree_grid), dim3(RT_BLOCK), lds, stream, T);
+            else hipLaunchKernelGGL(rt_tree_kernel<false>, dim3(tree_grid), dim3(RT_BLOCK), lds, stream, T);
+            RT_HIP(hipGetLastError());
+            if (t0 && t1) { RT_HIP(hipEventRecord(t1, stream)); s->tree_timers.emplace_back(t0, t1); }
+            uint32_t *tmp = list_in; list_in = list_out; list_out = tmp;
+            in_slots = parked;
+        }
         R.launch_spp = P.launch_spp;
         R.start_from_pixels = (accumulate || first > 0) ? 1 : 0;
         R.finish = (!accumulate && first + P.launch_spp >= spp) ? 1 : 0;
-        hipLaunchKernelGGL(rt_resolve_kernel, dim3(grid), dim3(RT_BLOCK), 0, stream, R);
+        hipLaunchKernelGGL(rt_resolve_kernel, dim3(resolve_grid), dim3(RT_BLOCK), 0, stream, R);
         RT_HIP(hipGetLastError());
         s->launches++;
     }
-    if (s->timers.size() > 2048) settle_timers(s);
+    if (s->timers.size() + s->tree_timers.size() > 4096) settle_timers(s);
     s->samples += (uint64_t)spp * own_rows * region.size.x;
     return RT_GPU_OK;
 }
@@ -767,7 +1048,9 @@ int rt_gpu_get_stats(rt_gpu_scene *s, rt_gpu_stats *out)
     out->rng_draws = w[9]; out->light_tests = w[10]; out->sphere_tests = w[11]; out->plane_tests = w[12];
     out->shade_steps = w[13]; out->pop_steps = w[14]; out->tri_steps = w[15];
     out->shade_lanes = w[16]; out->pop_lanes = w[17]; out->tri_lanes = w[18]; out->tree_entries = w[19];
-    out->kernel_ms = s->kernel_ms;
+    out->kernel_ms = s->kernel_ms + s->tree_ms;
+    out->shade_ms = s->kernel_ms; out->tree_ms = s->tree_ms;
+    out->rounds = s->rounds; out->overflowed = s->overflowed;
     out->launches = s->launches;
     return RT_GPU_OK;
 }
@@ -779,7 +1062,7 @@ int rt_gpu_reset_stats(rt_gpu_scene *s)
     RT_HIP(hipDeviceSynchronize());
     settle_timers(s);
     RT_HIP(hipMemset(s->d_stats, 0, sizeof(uint64_t) * RT_STAT_WORDS));
-    s->kernel_ms = 0.0; s->launches = 0; s->samples = 0;
+    s->kernel_ms = 0.0; s->tree_ms = 0.0; s->launches = 0; s->samples = 0; s->rounds = 0; s->overflowed = 0;
     return RT_GPU_OK;
 }
 

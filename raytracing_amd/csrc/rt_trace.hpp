@@ -291,6 +291,32 @@ __device__ __forceinline__ bool query_scan(const rt_dev_scene &S, f3 o, f3 d, co
     return false;
 }
 
+/* first instance from `first` on whose root box the ray enters (the test of
+ * query_scan without touching a stack), or -1 */
+template <bool STATS>
+__device__ __forceinline__ int query_probe(const rt_dev_scene &S, f3 o, f3 d, const Hit &h, int first, Counters &cn)
+{
+    for (int i = first; i < S.instance_count; i++) {
+        const rt_dev_instance &in = S.instances[i];
+        const rt_dev_mesh &m = S.meshes[in.mesh];
+        f3 rel = sub(o, ld3(in.pos));
+        f3 rx = ld3(in.rx), ry = ld3(in.ry), rz = ld3(in.rz);
+        f3 mo = mk(rx.x * rel.x + rx.y * rel.y + rx.z * rel.z,
+                   ry.x * rel.x + ry.y * rel.y + ry.z * rel.z,
+                   rz.x * rel.x + rz.y * rel.y + rz.z * rel.z);
+        f3 mu = mk(rx.x * d.x + rx.y * d.y + rx.z * d.z,
+                   ry.x * d.x + ry.y * d.y + ry.z * d.z,
+                   rz.x * d.x + rz.y * d.y + rz.z * d.z);
+        if (STATS) cn.root_tests++;
+        float enter, leave;
+        slab(ld3(m.root_lo), ld3(m.root_hi), mo, mu, enter, leave);
+        if (leave < enter) continue;
+        if (enter > h.t) continue;
+        return i;
+    }
+    return -1;
+}
+
 enum : int { STEP_MORE = 0, STEP_INSTANCE_DONE = 1, STEP_QUERY_DONE = 2 };
 
 /* one triangle of the current leaf: src/main.c:449-482 (precondition tv.tri_cur < tv.tri_end) */
@@ -460,7 +486,17 @@ __device__ __forceinline__ f3 texel(const rt_dev_scene &S, int texture, float u,
  */
 enum : int { EV_CAMERA = 0, EV_NEE = 1, EV_BOUNCE = 2, EV_TRACE_ONLY = 3 };
 enum : int { RAY_NONE = 0, RAY_SEGMENT = 1, RAY_SHADOW = 2 };
-enum : int { PH_SHADE = 0, PH_SCAN = 1, PH_TREE = 2, PH_DEAD = 3 };
+enum : int { PH_SHADE = 0, PH_SCAN = 1, PH_TREE = 2, PH_DEAD = 3, PH_PARK = 4 };
+
+/* A path in transit between the shade kernel and the tree kernel: 48 words.
+ * Words 0..15 (one 64-byte line) are all the tree kernel reads and writes:
+ *   0 flags: valid | ev<<1 | ray<<3 | inside<<5 | fresh<<6 | seg<<8      1 x | y<<16
+ *   2..4 origin   5..7 direction   8 t  9 type  10 id  11 inst  12 beta  13 gamma  14 material
+ *   15 instance to (re)start the walk at | light index<<16
+ * then 16..18 throughput, 19..21 radiance, 22..24 normal, 25..27 albedo, 28..30 direct,
+ * 31 lights reached, 32 reached here, 33 shadow length^2, 34 shadow cosine, 35..38 generator,
+ * 39 index of the sample's slot in the sample scratch. */
+#define RT_RECORD_WORDS 48
 
 template <class Rng, bool STATS>
 struct PathMachine {
@@ -677,6 +713,79 @@ struct PathMachine {
         }
         if (phase == PH_SCAN)
             phase = query_scan<STATS>(S, o, d, h, tv, stk, cn) ? PH_TREE : PH_SHADE;
+    }
+
+    /* ---- hand-over between kernels (counter generator only) ------------------- */
+    int park_inst;                /* PH_PARK: instance whose tree the ray has to walk first */
+
+    __device__ __forceinline__ void store_record(uint32_t *rec, uint32_t sample_index) const
+    {
+        uint4 *q = reinterpret_cast<uint4 *>(rec);
+        const uint32_t flags = 1u | ((uint32_t)ev << 1) | ((uint32_t)ray << 3) | ((uint32_t)inside_glass << 5) |
+                               ((uint32_t)rng.fresh << 6) | ((uint32_t)seg << 8);
+        q[0] = make_uint4(flags, x | (y << 16), __float_as_uint(o.x), __float_as_uint(o.y));
+        q[1] = make_uint4(__float_as_uint(o.z), __float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z));
+        q[2] = make_uint4(__float_as_uint(h.t), (uint32_t)h.type, h.id, h.inst);
+        q[3] = make_uint4(__float_as_uint(h.beta), __float_as_uint(h.gamma), (uint32_t)h.material,
+                          (uint32_t)park_inst | ((uint32_t)li << 16));
+        q[4] = make_uint4(__float_as_uint(throughput.x), __float_as_uint(throughput.y), __float_as_uint(throughput.z),
+                          __float_as_uint(radiance.x));
+        q[5] = make_uint4(__float_as_uint(radiance.y), __float_as_uint(radiance.z), __float_as_uint(n.x),
+                          __float_as_uint(n.y));
+        q[6] = make_uint4(__float_as_uint(n.z), __float_as_uint(albedo.x), __float_as_uint(albedo.y),
+                          __float_as_uint(albedo.z));
+        q[7] = make_uint4(__float_as_uint(direct.x), __float_as_uint(direct.y), __float_as_uint(direct.z),
+                          __float_as_uint(lights_reached));
+        q[8] = make_uint4(__float_as_uint(reached_here), __float_as_uint(shadow_len2), __float_as_uint(shadow_cos),
+                          rng.k0);
+        q[9] = make_uint4(rng.k1, rng.c0, rng.c1, sample_index);
+    }
+
+    /* false = the slot holds no path */
+    __device__ __forceinline__ bool load_record(const uint32_t *rec, uint32_t &sample_index)
+    {
+        const uint4 *q = reinterpret_cast<const uint4 *>(rec);
+        const uint4 a = q[0];
+        if (!(a.x & 1u)) return false;
+        const uint4 b = q[1], c = q[2], e = q[3], f = q[4], g = q[5], i = q[6], j = q[7], k = q[8], l = q[9];
+        ev = (int)((a.x >> 1) & 3u); ray = (int)((a.x >> 3) & 3u); inside_glass = ((a.x >> 5) & 1u) != 0;
+        rng.fresh = ((a.x >> 6) & 1u) != 0; seg = (int)(a.x >> 8);
+        x = a.y & 0xFFFFu; y = a.y >> 16;
+        o = mk(__uint_as_float(a.z), __uint_as_float(a.w), __uint_as_float(b.x));
+        d = mk(__uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+        h.t = __uint_as_float(c.x); h.type = (int)c.y; h.id = c.z; h.inst = c.w;
+        h.beta = __uint_as_float(e.x); h.gamma = __uint_as_float(e.y); h.material = (int)e.z; h.entered = false;
+        li = (int)(e.w >> 16);
+        throughput = mk(__uint_as_float(f.x), __uint_as_float(f.y), __uint_as_float(f.z));
+        radiance = mk(__uint_as_float(f.w), __uint_as_float(g.x), __uint_as_float(g.y));
+        n = mk(__uint_as_float(g.z), __uint_as_float(g.w), __uint_as_float(i.x));
+        albedo = mk(__uint_as_float(i.y), __uint_as_float(i.z), __uint_as_float(i.w));
+        direct = mk(__uint_as_float(j.x), __uint_as_float(j.y), __uint_as_float(j.z));
+        lights_reached = __uint_as_float(j.w);
+        reached_here = __uint_as_float(k.x); shadow_len2 = __uint_as_float(k.y); shadow_cos = __uint_as_float(k.z);
+        rng.k0 = k.w; rng.k1 = l.x; rng.c0 = l.y; rng.c1 = l.z;
+        sample_index = l.w;
+        phase = PH_SHADE;
+        return true;
+    }
+
+    /* shade step of the shade kernel: as shade_step, but a ray that enters an
+     * instance's root box is not walked here: the lane asks to be parked
+     * (PH_PARK, park_inst) and the tree kernel finishes the query. */
+    template <class OnEnd>
+    __device__ __forceinline__ void shade_step_park(OnEnd &&on_end)
+    {
+        if (book()) on_end();
+        if (phase == PH_SHADE) {
+            float tmax;
+            if (event(tmax)) on_end();
+            else if (ray != RAY_NONE) {
+                if (!query_begin<STATS>(S, o, d, tmax, ray == RAY_SHADOW, h, cn)) {
+                    park_inst = query_probe<STATS>(S, o, d, h, 0, cn);
+                    if (park_inst >= 0) phase = PH_PARK;
+                }
+            }
+        }
     }
 
     __device__ __forceinline__ bool wants_shade() const { return phase == PH_SHADE || phase == PH_SCAN; }
