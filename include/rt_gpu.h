@@ -153,10 +153,13 @@ int rt_gpu_get_stats(rt_gpu_scene *scene, rt_gpu_stats *out);
 int rt_gpu_reset_stats(rt_gpu_scene *scene);
 
 /* Self-test hook: evaluates the device's sin/cos/log/divide/sqrt building
- * blocks on n host floats (x, and y for the quotient x/y) so that a test can
- * compare them bit for bit with the host's.  Any output pointer may be NULL. */
+ * blocks on n host floats (x, and y for the quotients x/y) so that a test can
+ * compare them bit for bit with the host's.  div_cached_out receives x/y as the
+ * tree kernel computes it for box tests (reciprocal refined once per ray).  Any
+ * output pointer may be NULL. */
 int rt_gpu_eval_math(const float *x, const float *y, size_t n,
-                     float *sin_out, float *cos_out, float *log_out, float *div_out, float *sqrt_out);
+                     float *sin_out, float *cos_out, float *log_out, float *div_out, float *sqrt_out,
+                     float *div_cached_out);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,8 @@ struct rt_dev_mesh {                     /* one per distinct host Mesh */
     uint32_t tri_base;                   /* entries and object ids are mesh-local; add this for tris/attrs */
     uint32_t node_base;
     uint32_t stack_need;                 /* deepest level + 2 */
+    uint32_t tame_boxes;                 /* 1: every box coordinate is 0 or has magnitude in [2^-40, 2^40] */
+    uint32_t pad[3];
 };
 
 struct rt_dev_instance {                 /* one per Scene_Mesh */

@@ -254,6 +254,18 @@ int rt_flatten_scene(const rt_scene *scene, rt_flat_scene &out)
 
             MeshWalk walk{mesh, out, dm.node_base};
             if (!walk.run(&dm.root_entry)) { out.error = walk.error; return -2; }
+            {   /* are all box coordinates in the range where the kernels' shared-reciprocal slab test is exact? */
+                auto tame = [](float v) { float a = std::fabs(v); return v == 0.0f || (a >= 0x1p-40f && a <= 0x1p40f); };
+                bool ok = true;
+                for (int k = 0; k < 3; k++) ok = ok && tame(dm.root_lo[k]) && tame(dm.root_hi[k]);
+                for (size_t n = dm.node_base; ok && n < out.nodes.size(); n++) {
+                    const rt_dev_node &nd = out.nodes[n];
+                    if (nd.flags & RT_NODE_PSEUDO) continue;
+                    for (int k = 0; k < 3; k++)
+                        ok = ok && tame(nd.lo0[k]) && tame(nd.hi0[k]) && tame(nd.lo1[k]) && tame(nd.hi1[k]);
+                }
+                dm.tame_boxes = ok ? 1u : 0u;
+            }
             dm.stack_need = walk.deepest + 2 + (walk.chained ? 2 : 0);
             if (dm.stack_need > out.stack_cap) out.stack_cap = dm.stack_need;
             found = mesh_index.emplace(mesh, (uint32_t)out.meshes.size()).first;

@@ -83,6 +83,9 @@ __device__ __forceinline__ void flush_counters(const rt::Counters &cn, uint64_t 
  * operations of the host's nested loops in the same order whatever lane or
  * launch runs them, so results do not change.
  * ------------------------------------------------------------------------ */
+#ifndef RT_TREE_REFILL
+#define RT_TREE_REFILL 16             /* tree kernel: free lanes needed before the wave fetches new rays */
+#endif
 #define RT_CHUNK 256u                /* parked-list slots a wave reserves per atomic */
 
 struct QueueCounters {               /* device words, zeroed per launch where noted */
@@ -273,8 +276,10 @@ rt_tree_kernel(const TreeParams P)
     };
 
     for (;;) {
-        /* ---- free lanes take the next parked rays ---------------------------------- */
-        while (!input_done) {
+        /* ---- free lanes take the next parked rays; wait until a quarter of the wave is free so
+         * that loading a record and testing its root box does not run for one or two lanes ---- */
+        const int n_free = __popcll(__ballot(!busy));
+        while (!input_done && (n_free >= RT_TREE_REFILL || n_free == 64)) {
             const unsigned long long need = __ballot(!busy);
             if (!need) break;
             if (in_cur >= in_end) {
@@ -301,7 +306,7 @@ rt_tree_kernel(const TreeParams P)
                     tv.inst = (int)(e.w & 0xFFFFu);
                     busy = true;
                     if (STATS) cn.root_tests--;          /* the shade kernel already counted this root test */
-                    if (!rt::query_scan<STATS>(P.S, o, d, h, tv, stk, cn)) finish();
+                    if (!rt::query_scan<STATS, true>(P.S, o, d, h, tv, stk, cn)) finish();
                 }
             }
             in_cur += (uint32_t)__popcll(need);
@@ -320,11 +325,11 @@ rt_tree_kernel(const TreeParams P)
             if (want_tri) r = rt::query_tri_step<STATS>(P.S, any_hit, h, tv, cn);
         } else {
             if (STATS) { if (lane == 0) cn.pop_steps++; if (busy && !want_tri) cn.pop_lanes++; }
-            if (busy && !want_tri) r = rt::query_pop_step<STATS>(P.S, h, tv, stk, cn);
+            if (busy && !want_tri) r = rt::query_pop_step<STATS, true>(P.S, h, tv, stk, cn);
         }
         if (r == rt::STEP_QUERY_DONE) finish();
         else if (r == rt::STEP_INSTANCE_DONE) {
-            if (!(tv.inst < P.S.instance_count) || !rt::query_scan<STATS>(P.S, o, d, h, tv, stk, cn)) finish();
+            if (!(tv.inst < P.S.instance_count) || !rt::query_scan<STATS, true>(P.S, o, d, h, tv, stk, cn)) finish();
         }
     }
     flush_counters<STATS>(cn, P.stats);
@@ -475,7 +480,7 @@ __global__ void rt_normalize_kernel(float *p, size_t n, float factor)
 }
 
 __global__ void rt_math_kernel(const float *x, const float *y, size_t n, float *s, float *c, float *l,
-                               float *q, float *r)
+                               float *q, float *r, float *qc)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -485,6 +490,7 @@ __global__ void rt_math_kernel(const float *x, const float *y, size_t n, float *
     if (c) c[i] = cs;
     if (l) l[i] = rt_logf(x[i]);
     if (q && y) q[i] = x[i] / y[i];
+    if (qc && y) qc[i] = (rt::tame(y[i]) && rt::tame_or_zero(x[i])) ? rt::div_by_cached(x[i], y[i], rt::refined_rcp(y[i])) : x[i] / y[i];
     if (r) r[i] = __builtin_sqrtf(x[i]);
 }
 
@@ -848,6 +854,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
             s->overflowed += qc.overflow;
             s->rounds++;
             uint32_t parked = qc.out_reserved < capacity ? qc.out_reserved : (uint32_t)capacity;
+            if (getenv("RT_GPU_TRACE_ROUNDS")) fprintf(stderr, "round %u: in %u slots -> parked %u slots, overflow %u\n", round, in_slots, parked, qc.overflow);
             if (parked == 0) break;
             /* answer the parked queries, then resume those paths */
             TreeParams T;
@@ -1067,15 +1074,15 @@ int rt_gpu_reset_stats(rt_gpu_scene *s)
 }
 
 int rt_gpu_eval_math(const float *x, const float *y, size_t n, float *sin_out, float *cos_out, float *log_out,
-                     float *div_out, float *sqrt_out)
+                     float *div_out, float *sqrt_out, float *div_cached_out)
 {
     if (!x) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_eval_math: NULL argument");
     if (!n) return RT_GPU_OK;
-    float *d[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float *d[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const float *hin[2] = {x, y};
-    float *hout[5] = {sin_out, cos_out, log_out, div_out, sqrt_out};
+    float *hout[6] = {sin_out, cos_out, log_out, div_out, sqrt_out, div_cached_out};
     hipError_t e = hipSuccess;
-    for (int i = 0; i < 7 && e == hipSuccess; i++) {
+    for (int i = 0; i < 8 && e == hipSuccess; i++) {
         bool wanted = i < 2 ? hin[i] != nullptr : hout[i - 2] != nullptr;
         if (!wanted) continue;
         e = hipMalloc(reinterpret_cast<void **>(&d[i]), n * sizeof(float));
@@ -1083,13 +1090,13 @@ int rt_gpu_eval_math(const float *x, const float *y, size_t n, float *sin_out, f
     }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(rt_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr,
-                           d[0], d[1], n, d[2], d[3], d[4], d[5], d[6]);
+                           d[0], d[1], n, d[2], d[3], d[4], d[5], d[6], d[7]);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
-    for (int i = 2; i < 7 && e == hipSuccess; i++)
+    for (int i = 2; i < 8 && e == hipSuccess; i++)
         if (d[i]) e = hipMemcpy(hout[i - 2], d[i], n * sizeof(float), hipMemcpyDeviceToHost);
-    for (int i = 0; i < 7; i++) if (d[i]) (void)hipFree(d[i]);
+    for (int i = 0; i < 8; i++) if (d[i]) (void)hipFree(d[i]);
     if (e != hipSuccess) return fail(RT_GPU_ERR_DEVICE, std::string("math probe: ") + hipGetErrorString(e));
     return RT_GPU_OK;
 }

@@ -180,6 +180,55 @@ __device__ __forceinline__ void slab(f3 lo, f3 hi, f3 o, f3 d, float &enter, flo
     leave = sel_min(sel_min(fx, fy), fz);
 }
 
+/* ---- the same slab test with the divisor's reciprocal computed once per ray ----
+ *
+ * hipcc expands the IEEE quotient a/b (no scaling needed, see below) into
+ *   y0 = rcp(b); e = fma(-b,y0,1); y1 = fma(e,y0,y0);                 <- depends on b only
+ *   q0 = a*y1; r0 = fma(-b,q0,a); q1 = fma(r0,y1,q0); r1 = fma(-b,q1,a); q = fma(r1,y1,q1)
+ * A tree walk divides by the same three direction components at every node,
+ * so y1 is kept per ray and each quotient costs the second line only: the very
+ * same operations, hence the very same bits.  The expansion's pre-scaling
+ * (v_div_scale) and special-case fix-up (v_div_fixup) do nothing when b is
+ * normal with |b| in [2^-40, 2^40] and a is 0 or has |a| in [2^-63, 2^41]
+ * (then |a/b| lies in [2^-103, 2^81]); rays or meshes outside that range take
+ * the plain division.  The one difference, the sign of a zero quotient, cannot
+ * change a comparison, and comparisons are all a slab test is used for. */
+__device__ __forceinline__ float refined_rcp(float b)
+{
+    float y0 = __builtin_amdgcn_rcpf(b);
+    float e = __builtin_fmaf(-b, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+__device__ __forceinline__ float div_by_cached(float a, float b, float y1)
+{
+    float q0 = a * y1;
+    float r0 = __builtin_fmaf(-b, q0, a);
+    float q1 = __builtin_fmaf(r0, y1, q0);
+    float r1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(r1, y1, q1);
+}
+__device__ __forceinline__ bool tame_or_zero(float v)
+{
+    float a = __builtin_fabsf(v);
+    return v == 0.0f || (a >= 0x1p-40f && a <= 0x1p40f);
+}
+__device__ __forceinline__ bool tame(float v)
+{
+    float a = __builtin_fabsf(v);
+    return a >= 0x1p-40f && a <= 0x1p40f;
+}
+__device__ __forceinline__ void slab_cached(f3 lo, f3 hi, f3 o, f3 d, f3 y, float &enter, float &leave)
+{
+    float ax = div_by_cached(lo.x - o.x, d.x, y.x), ay = div_by_cached(lo.y - o.y, d.y, y.y),
+          az = div_by_cached(lo.z - o.z, d.z, y.z);
+    float bx = div_by_cached(hi.x - o.x, d.x, y.x), by = div_by_cached(hi.y - o.y, d.y, y.y),
+          bz = div_by_cached(hi.z - o.z, d.z, y.z);
+    float nx = sel_min(ax, bx), ny = sel_min(ay, by), nz = sel_min(az, bz);
+    float fx = sel_max(ax, bx), fy = sel_max(ay, by), fz = sel_max(az, bz);
+    enter = sel_max(sel_max(nx, ny), nz);
+    leave = sel_min(sel_min(fx, fy), fz);
+}
+
 /* ball test shared by lights and spheres, src/main.c:283-308 */
 __device__ __forceinline__ bool ball(f3 center, float radius, f3 o, f3 d, float best, float &t_out, bool &entered)
 {
@@ -218,6 +267,8 @@ struct Trav {
     int top;                     /* stack pointer, -1 = empty */
     int inst;                    /* instance being walked / next to scan */
     int material;
+    f3 inv;                      /* refined reciprocals of mu (only if cached) */
+    bool cached;                 /* the shared-reciprocal slab test is exact for this ray and mesh */
 };
 
 template <bool STATS>
@@ -260,8 +311,9 @@ __device__ __forceinline__ bool query_begin(const rt_dev_scene &S, f3 o, f3 d, f
     return S.instance_count == 0;
 }
 
-/* from instance tv.inst on: true = tv is set up to walk an instance, false = no instance left */
-template <bool STATS>
+/* from instance tv.inst on: true = tv is set up to walk an instance, false = no instance left.
+ * CACHE: prepare the per-ray reciprocals for slab_cached when ray and mesh allow it. */
+template <bool STATS, bool CACHE = false>
 __device__ __forceinline__ bool query_scan(const rt_dev_scene &S, f3 o, f3 d, const Hit &h, Trav &tv,
                                            Stack stk, Counters &cn)
 {
@@ -284,6 +336,12 @@ __device__ __forceinline__ bool query_scan(const rt_dev_scene &S, f3 o, f3 d, co
         if (enter > h.t) continue;
         tv.node_base = m.node_base; tv.tri_base = m.tri_base; tv.material = in.material;
         tv.top = 0; tv.tri_cur = 0; tv.tri_end = 0;
+        tv.cached = false;
+        if (CACHE) {
+            tv.cached = m.tame_boxes != 0u && tame(tv.mu.x) && tame(tv.mu.y) && tame(tv.mu.z) &&
+                        tame_or_zero(tv.mo.x) && tame_or_zero(tv.mo.y) && tame_or_zero(tv.mo.z);
+            tv.inv = mk(refined_rcp(tv.mu.x), refined_rcp(tv.mu.y), refined_rcp(tv.mu.z));
+        }
         stk.at(0) = m.root_entry;
         if (STATS) cn.tree_entries++;
         return true;
@@ -346,7 +404,7 @@ __device__ __forceinline__ int query_tri_step(const rt_dev_scene &S, bool any_hi
 }
 
 /* one stack pop: src/main.c:397-447 (precondition: no triangle pending) */
-template <bool STATS>
+template <bool STATS, bool CACHE = false>
 __device__ __forceinline__ int query_pop_step(const rt_dev_scene &S, Hit &h, Trav &tv, Stack stk, Counters &cn)
 {
     if (tv.top < 0) { tv.inst++; return STEP_INSTANCE_DONE; }
@@ -367,8 +425,13 @@ __device__ __forceinline__ int query_pop_step(const rt_dev_scene &S, Hit &h, Tra
     }
     if (STATS) cn.interior_pops++;
     float e0, l0, e1, l1;
-    slab(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), tv.mo, tv.mu, e0, l0);
-    slab(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), tv.mo, tv.mu, e1, l1);
+    if (CACHE && tv.cached) {
+        slab_cached(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), tv.mo, tv.mu, tv.inv, e0, l0);
+        slab_cached(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), tv.mo, tv.mu, tv.inv, e1, l1);
+    } else {
+        slab(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), tv.mo, tv.mu, e0, l0);
+        slab(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), tv.mo, tv.mu, e1, l1);
+    }
     bool h0 = (e0 < l0) && (e0 < h.t);           /* strict: a flat box is never entered */
     bool h1 = (e1 < l1) && (e1 < h.t);
     if (h0 && h1) {                              /* farther child first, nearer on top; ties: child 0 on top */

@@ -88,7 +88,7 @@ def lib():
         L.rt_gpu_quantize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.rt_gpu_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.rt_gpu_reset_stats.argtypes = [C.c_void_p]
-        L.rt_gpu_eval_math.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 5
+        L.rt_gpu_eval_math.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
         _LIB = L
     return _LIB
 
@@ -172,12 +172,13 @@ def eval_math(x, y=None):
     """Device sin, cos, log, x/y, sqrt of float arrays (self-test hook)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     n = x.size
-    outs = [np.zeros(n, dtype=np.float32) for _ in range(5)]
+    outs = [np.zeros(n, dtype=np.float32) for _ in range(6)]
     yp = None
     if y is not None:
         y = np.ascontiguousarray(y, dtype=np.float32)
         yp = y.ctypes.data
     _check(lib().rt_gpu_eval_math(x.ctypes.data, yp, n, outs[0].ctypes.data, outs[1].ctypes.data,
                                   outs[2].ctypes.data, outs[3].ctypes.data if y is not None else None,
-                                  outs[4].ctypes.data))
-    return dict(sin=outs[0], cos=outs[1], log=outs[2], div=outs[3] if y is not None else None, sqrt=outs[4])
+                                  outs[4].ctypes.data, outs[5].ctypes.data if y is not None else None))
+    return dict(sin=outs[0], cos=outs[1], log=outs[2], div=outs[3] if y is not None else None, sqrt=outs[4],
+                div_cached=outs[5] if y is not None else None)

@@ -66,6 +66,18 @@ def test_device_math_equals_host_math(golden):
         m = gpu.eval_math(x, y)
         assert L.same_bits(m["div"], x / y).all()
         assert L.same_bits(gpu.eval_math(np.abs(x))["sqrt"], np.sqrt(np.abs(x))).all()
+        # the box test's quotient with the per-ray refined reciprocal: same bits as the IEEE quotient
+        # (a zero may differ in sign, which no comparison can see)
+        for lo, hi in ((-40, 40), (-3, 3), (-12, 2)):
+            a = (rng.standard_normal(1 << 22) * 2.0 ** rng.uniform(lo, hi, 1 << 22)).astype(np.float32)
+            b = (rng.standard_normal(1 << 22) * 2.0 ** rng.uniform(lo, hi, 1 << 22)).astype(np.float32)
+            a[::97] = 0.0
+            b[::89] = (b[::89].view(np.uint32) | np.uint32(0x007FFFFF)).view(np.float32)     # all-ones mantissas
+            a[::83] = (b[::83] * np.float32(3.0)).astype(np.float32)                          # exact / near-exact quotients
+            got = gpu.eval_math(a, b)["div_cached"]
+            want = a / b
+            same = L.same_bits(got, want) | ((got == 0) & (want == 0))
+            assert same.all(), int((~same).sum())
 
 
 # ---------------------------------------------------------------- find_ray_hit
