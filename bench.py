@@ -12,10 +12,15 @@ bands into a packed buffer and one all-gather over xGMI assembles the frame on e
 The frame is the same whatever N is (the generator is keyed by pixel and sample), so this is
 strong scaling of a fixed frame.
 
-Rank 0 prints one JSON line.  `roofline` prices the render kernel against HBM bandwidth with
-the ALGORITHMIC bytes of the traversal (bytes the reference's data structures would move for
-the primitives, boxes, triangles, attributes and texels the kernel actually tested, counted
-by the device), divided by the kernel's own duration measured with HIP events on its stream.
+Rank 0 prints one JSON line.  A frame is rendered by two kernels that alternate: rt_shade_kernel
+(path bookkeeping, sampling, the scene's lights/spheres/planes, instance root boxes) and
+rt_tree_kernel (mesh tree walks for the rays the shade kernel parked), a few dozen launches per
+frame.  `roofline` prices them against HBM bandwidth with the ALGORITHMIC bytes of the path (bytes
+the reference's data structures would move for the primitives, boxes, triangles, attributes and
+texels the kernels actually tested, counted on the device), divided by the kernels' own duration
+measured with HIP events on their stream: the top-level figure is the whole frame (all launches of
+both kernels), `kernels` splits bytes and time per kernel and gives the average launch duration
+that a rocprofv3 kernel trace of the same command shows.
 `cpu_baseline` times the reference itself (compiled from its own sources with its build.sh
 flags, oracle/_ref) on this machine's host cores over a bounded number of samples of the same
 scene; when that library is absent it times the CPU oracle port instead.
@@ -36,15 +41,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 
 
-def algorithmic_bytes(st, scene, pixels):
-    """Bytes the reference's records would move for the work the kernel counted:
+def algorithmic_bytes(st, pixels):
+    """Bytes the reference's records would move for the work the kernels counted, per kernel:
     Light 32, Sphere 20, Plane 20 per primitive tested; Transform 48 + root box 24 per instance
-    root test; two child Mesh_Nodes (2 x 40) per interior pop; Triangle 36 + 3 points 36 per
-    triangle test; 3 normals + 3 uvs (60) per triangle hit; one 12-byte texel per lookup; one
-    12-byte pixel store per pixel."""
-    return (32 * st["light_tests"] + 20 * st["sphere_tests"] + 20 * st["plane_tests"] +
-            72 * st["root_tests"] + 80 * st["interior_pops"] + 72 * st["tri_tests"] +
-            60 * st["tri_hits"] + 12 * st["tex_lookups"] + 12 * pixels)
+    root test; 3 normals + 3 uvs (60) per triangle hit; one 12-byte texel per lookup; one 12-byte
+    pixel store per pixel (shade kernel); two child Mesh_Nodes (2 x 40) per interior pop and
+    Triangle 36 + 3 points 36 per triangle test (tree kernel)."""
+    shade = (32 * st["light_tests"] + 20 * st["sphere_tests"] + 20 * st["plane_tests"] +
+             72 * st["root_tests"] + 60 * st["tri_hits"] + 12 * st["tex_lookups"] + 12 * pixels)
+    tree = 80 * st["interior_pops"] + 72 * st["tri_tests"]
+    return shade, tree
 
 
 def cpu_baseline(sh, width, height, target_seconds=12.0):
@@ -162,22 +168,26 @@ def main():
 
     # max over ranks of the time, sum over ranks of the rays
     rays = float(st["rays"])
-    kernel_ms = st["kernel_ms"] / max(1, st["launches"])
+    frames = max(1, st["launches"])
+    shade_ms, tree_ms = st["shade_ms"] / frames, st["tree_ms"] / frames
+    shade_launches, tree_launches = st["rounds"] / frames, max(0.0, st["rounds"] / frames - 1)
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, shade_ms, tree_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         r = torch.tensor([rays], dtype=torch.float64, device="cuda")
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        elapsed, kernel_ms, rays = float(t[0]), float(t[1]), float(r[0])
+        elapsed, shade_ms, tree_ms, rays = float(t[0]), float(t[1]), float(t[2]), float(r[0])
+    kernel_ms = shade_ms + tree_ms
 
-    # algorithmic bytes of ONE launch: the same frame (seed 0) with the detailed counters on, untimed
+    # algorithmic bytes of ONE frame: the same frame (seed 0) with the detailed counters on, untimed
     g.reset_stats()
     step(0, gpu.Options(max_segments=args.max_segments, flags=opts.flags | gpu.FLAG_DETAILED_STATS,
                         band_rows=opts.band_rows, band_rank=opts.band_rank, band_count=opts.band_count))
     torch.cuda.synchronize()
     det = g.stats()
     own_pixels = (H // world) * W
-    abytes = algorithmic_bytes(det, sh, own_pixels)
+    shade_bytes, tree_bytes = algorithmic_bytes(det, own_pixels)
+    abytes = shade_bytes + tree_bytes
     checksum = float(frame.double().sum().item())
 
     if rank == 0:
@@ -212,9 +222,21 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
-                "kernel": "rt_render_pixels_kernel",
+                "kernel": "rt_shade_kernel + rt_tree_kernel, all launches of one frame",
                 "kernel_ms": round(kernel_ms, 3),
-                "algorithmic_bytes_per_launch": int(abytes),
+                "kernels": {
+                    "rt_shade_kernel": {
+                        "ms_per_frame": round(shade_ms, 3), "launches_per_frame": round(shade_launches, 2),
+                        "avg_launch_ms": round(shade_ms / max(1.0, shade_launches), 4),
+                        "algorithmic_bytes": int(shade_bytes),
+                        "achieved": round(shade_bytes / max(1e-9, shade_ms * 1e-3) / 1e9, 1)},
+                    "rt_tree_kernel": {
+                        "ms_per_frame": round(tree_ms, 3), "launches_per_frame": round(tree_launches, 2),
+                        "avg_launch_ms": round(tree_ms / max(1.0, tree_launches), 4),
+                        "algorithmic_bytes": int(tree_bytes),
+                        "achieved": round(tree_bytes / max(1e-9, tree_ms * 1e-3) / 1e9, 1)},
+                },
+                "algorithmic_bytes_per_frame": int(abytes),
                 "algorithmic_bytes_per_ray": round(abytes / max(1, det["rays"]), 1),
                 "counted": {k: int(det[k]) for k in ("rays", "shadow_rays", "root_tests", "interior_pops",
                                                      "tri_tests", "tri_hits", "tex_lookups", "light_tests",

@@ -116,8 +116,7 @@ template <bool FRESH, bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_shade_kernel(const ShadeParams P)
 {
-    extern __shared__ uint32_t lds[];
-    rt::Stack stk; stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK;     /* used only on list overflow */
+    rt::Stack stk; stk.base = nullptr; stk.stride = 0;                      /* this kernel walks no tree */
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -191,6 +190,7 @@ rt_shade_kernel(const ShadeParams P)
         if (!__ballot(has)) break;                       /* nothing in flight and no input left */
 
         /* ---- 2. one shade step ---------------------------------------------------- */
+        if (STATS) { if (lane == 0) cn.shade_steps++; if (has) cn.shade_lanes++; }
         if (has) {
             pm.shade_step_park([&]() {
                 const rt::f3 c = pm.path_value();
@@ -217,19 +217,11 @@ rt_shade_kernel(const ShadeParams P)
                 uint32_t slot = rank < room ? out_cur + rank : next_base + (rank - room);
                 if (slot < P.out_capacity) {
                     pm.store_record(P.out_list + (size_t)slot * RT_RECORD_WORDS, sample_index);
-                    has = false;
-                    pm.phase = rt::PH_DEAD;
-                } else {                                  /* list full: walk the tree right here (slow, still exact) */
+                } else {                                  /* cannot happen: the host sizes the lists for every path of the launch */
                     atomicAdd(&P.q->overflow, 1u);
-                    pm.tv.inst = pm.park_inst;
-                    while (rt::query_scan<STATS>(P.S, pm.o, pm.d, pm.h, pm.tv, stk, cn)) {
-                        int r;
-                        do { r = rt::query_step<STATS>(P.S, pm.ray == rt::RAY_SHADOW, pm.h, pm.tv, stk, cn); }
-                        while (r == rt::STEP_MORE);
-                        if (r == rt::STEP_QUERY_DONE) break;
-                    }
-                    pm.phase = rt::PH_SHADE;
                 }
+                has = false;
+                pm.phase = rt::PH_DEAD;
             }
             if (count > room) { out_cur = next_base + (count - room); out_end = next_base + RT_CHUNK; }
             else out_cur += count;
@@ -651,7 +643,7 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
         {   /* persistent grids: as many workgroups as the device keeps resident */
             const size_t lds_bytes = (size_t)RT_BLOCK * flat.stack_cap * 4;
             int per_cu_shade = 0, per_cu_tree = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, rt_shade_kernel<true, false>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_shade < 1) per_cu_shade = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, rt_shade_kernel<true, false>, RT_BLOCK, 0) != hipSuccess || per_cu_shade < 1) per_cu_shade = 1;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tree, rt_tree_kernel<false>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_tree < 1) per_cu_tree = 1;
             s->shade_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_shade);
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
@@ -805,21 +797,25 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     R.norm = rt_pixel_norm((o && o->spp_total) ? o->spp_total : spp);
 
     /* how many samples per pixel one launch carries: bounded by the sample scratch (12 bytes per
-     * item) and by the parked lists (2 x 192 bytes per item that can be in flight) */
+     * item) and by the two parked lists (192 bytes per record each).  A list has room for every
+     * path of the launch at once plus one partly used chunk per wave, so parking never fails. */
     const uint64_t units = (uint64_t)G.blocks_x * G.block_rows;
     const uint64_t items_per_sample = units * 64;
-    uint64_t scratch_mb = 4096, parked_mb = 12288;
+    const uint64_t chunk_slack = (uint64_t)s->shade_blocks * (RT_BLOCK / 64) * RT_CHUNK;
+    uint64_t scratch_mb = 4096, parked_mb = 32768;
     if (const char *e = getenv("RT_GPU_SCRATCH_MB")) scratch_mb = (uint64_t)atoll(e);
     if (const char *e = getenv("RT_GPU_PARKED_MB")) parked_mb = (uint64_t)atoll(e);
     uint64_t per_launch = (scratch_mb << 20) / (items_per_sample * 12);
-    if (per_launch < 1) per_launch = 1;
+    const uint64_t list_records = ((parked_mb << 20) / 2) / (RT_RECORD_WORDS * 4);
+    if (list_records < items_per_sample + chunk_slack)
+        return fail(RT_GPU_ERR_MEMORY, "RT_GPU_PARKED_MB is too small for one sample per pixel of this region");
+    if (per_launch > (list_records - chunk_slack) / items_per_sample) per_launch = (list_records - chunk_slack) / items_per_sample;
     if (per_launch > spp) per_launch = spp;
     if (per_launch * items_per_sample > 0xFFFFFF00ull / 3) per_launch = (0xFFFFFF00ull / 3) / items_per_sample;
     if (per_launch < 1) return fail(RT_GPU_ERR_ARGUMENT, "region too large for one launch");
-    uint64_t capacity = ((parked_mb << 20) / 2) / (RT_RECORD_WORDS * 4);       /* records per list */
-    if (capacity > per_launch * items_per_sample) capacity = per_launch * items_per_sample;
+    uint64_t capacity = per_launch * items_per_sample + chunk_slack;
     capacity = (capacity + RT_CHUNK - 1) / RT_CHUNK * RT_CHUNK;
-    if (capacity > 0xFFFFFF00ull) capacity = 0xFFFFFF00ull / RT_CHUNK * RT_CHUNK;
+    if (capacity > 0xFFFFFF00ull) return fail(RT_GPU_ERR_ARGUMENT, "region too large for one launch");
     rc = ensure_scratch(s, per_launch * items_per_sample * 12, capacity);
     if (rc) return rc;
     P.samples = s->d_samples; R.samples = s->d_samples;
@@ -840,11 +836,11 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
             hipEvent_t e0 = take_event(s), e1 = take_event(s);
             if (e0 && e1) RT_HIP(hipEventRecord(e0, stream));
             if (round == 0) {
-                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<true, true>), dim3(shade_grid), dim3(RT_BLOCK), lds, stream, P);
-                else hipLaunchKernelGGL((rt_shade_kernel<true, false>), dim3(shade_grid), dim3(RT_BLOCK), lds, stream, P);
+                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<true, true>), dim3(shade_grid), dim3(RT_BLOCK), 0, stream, P);
+                else hipLaunchKernelGGL((rt_shade_kernel<true, false>), dim3(shade_grid), dim3(RT_BLOCK), 0, stream, P);
             } else {
-                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<false, true>), dim3(shade_grid), dim3(RT_BLOCK), lds, stream, P);
-                else hipLaunchKernelGGL((rt_shade_kernel<false, false>), dim3(shade_grid), dim3(RT_BLOCK), lds, stream, P);
+                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<false, true>), dim3(shade_grid), dim3(RT_BLOCK), 0, stream, P);
+                else hipLaunchKernelGGL((rt_shade_kernel<false, false>), dim3(shade_grid), dim3(RT_BLOCK), 0, stream, P);
             }
             RT_HIP(hipGetLastError());
             if (e0 && e1) { RT_HIP(hipEventRecord(e1, stream)); s->timers.emplace_back(e0, e1); }
@@ -853,6 +849,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
             RT_HIP(hipStreamSynchronize(stream));
             s->overflowed += qc.overflow;
             s->rounds++;
+            if (qc.overflow) return fail(RT_GPU_ERR_DEVICE, "parked-path list overflow (" + std::to_string(qc.overflow) + " paths lost)");
             uint32_t parked = qc.out_reserved < capacity ? qc.out_reserved : (uint32_t)capacity;
             if (getenv("RT_GPU_TRACE_ROUNDS")) fprintf(stderr, "round %u: in %u slots -> parked %u slots, overflow %u\n", round, in_slots, parked, qc.overflow);
             if (parked == 0) break;

@@ -31,6 +31,15 @@ struct f3 { float x, y, z; };
 
 __device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ f3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
+
+/* Small scene tables (lights, spheres, planes, instances, meshes) never change while a kernel
+ * runs.  Reading them through a constant-address-space pointer with a wave-uniform index lets the
+ * compiler fetch them with scalar loads into SGPRs; through a plain global pointer it must assume
+ * the kernel's own stores could alias them and issues a vector load per lane. */
+#define RT_CMEM __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const RT_CMEM T *cmem(const T *p) { return (const RT_CMEM T *)(p); }
+__device__ __forceinline__ f3 ld3(const RT_CMEM float *p) { return mk(p[0], p[1], p[2]); }
 /* dot: ((0 + x) + y) + z like src/math.c:3-12 (the leading +0 turns a -0 product into +0) */
 __device__ __forceinline__ float dot(f3 a, f3 b)
 {
@@ -280,8 +289,11 @@ __device__ __forceinline__ bool query_begin(const rt_dev_scene &S, f3 o, f3 d, f
     cn.rays++;
     if (STATS && any_hit) cn.shadow_rays++;
 
+    const RT_CMEM rt_dev_light *lights = cmem(S.lights);
+    const RT_CMEM rt_dev_sphere *spheres = cmem(S.spheres);
+    const RT_CMEM rt_dev_plane *planes = cmem(S.planes);
     for (int i = 0; i < S.light_count; i++) {
-        const rt_dev_light &l = S.lights[i];
+        const RT_CMEM rt_dev_light &l = lights[i];
         float t;
         if (STATS) cn.light_tests++;
         if (ball(ld3(l.c), l.radius, o, d, h.t, t, h.entered)) {
@@ -290,7 +302,7 @@ __device__ __forceinline__ bool query_begin(const rt_dev_scene &S, f3 o, f3 d, f
         }
     }
     for (int i = 0; i < S.sphere_count; i++) {
-        const rt_dev_sphere &s = S.spheres[i];
+        const RT_CMEM rt_dev_sphere &s = spheres[i];
         float t;
         if (STATS) cn.sphere_tests++;
         if (ball(ld3(s.c), s.radius, o, d, h.t, t, h.entered)) {
@@ -299,7 +311,7 @@ __device__ __forceinline__ bool query_begin(const rt_dev_scene &S, f3 o, f3 d, f
         }
     }
     for (int i = 0; i < S.plane_count; i++) {                        /* src/main.c:355-369 */
-        const rt_dev_plane &p = S.planes[i];
+        const RT_CMEM rt_dev_plane &p = planes[i];
         f3 n = ld3(p.n);
         if (STATS) cn.plane_tests++;
         float t = (p.d - dot(o, n)) / dot(d, n);
@@ -354,9 +366,11 @@ __device__ __forceinline__ bool query_scan(const rt_dev_scene &S, f3 o, f3 d, co
 template <bool STATS>
 __device__ __forceinline__ int query_probe(const rt_dev_scene &S, f3 o, f3 d, const Hit &h, int first, Counters &cn)
 {
+    const RT_CMEM rt_dev_instance *instances = cmem(S.instances);
+    const RT_CMEM rt_dev_mesh *meshes = cmem(S.meshes);
     for (int i = first; i < S.instance_count; i++) {
-        const rt_dev_instance &in = S.instances[i];
-        const rt_dev_mesh &m = S.meshes[in.mesh];
+        const RT_CMEM rt_dev_instance &in = instances[i];
+        const RT_CMEM rt_dev_mesh &m = meshes[in.mesh];
         f3 rel = sub(o, ld3(in.pos));
         f3 rx = ld3(in.rx), ry = ld3(in.ry), rz = ld3(in.rz);
         f3 mo = mk(rx.x * rel.x + rx.y * rel.y + rx.z * rel.z,

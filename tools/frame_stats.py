@@ -19,6 +19,7 @@ for detailed in (False, True):
           f"rounds {st['rounds']}, overflowed {st['overflowed']}, rays {st['rays']/1e6:.1f} M")
     if detailed:
         print({k: st[k] for k in ("tree_entries", "interior_pops", "leaf_pops", "tri_tests", "root_tests")})
-        for kind in ("pop", "tri"):
+        print({k: st[k] for k in ("samples", "rays", "shadow_rays", "rng_draws", "light_tests", "plane_tests", "tri_hits")})
+        for kind in ("shade", "pop", "tri"):
             steps, lanes = st[kind + "_steps"], st[kind + "_lanes"]
             print(f"  {kind}: {steps} wave steps, {lanes / max(1, steps):.1f} lanes per step")
