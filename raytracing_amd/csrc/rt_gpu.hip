@@ -86,6 +86,9 @@ __device__ __forceinline__ void flush_counters(const rt::Counters &cn, uint64_t 
 #ifndef RT_TREE_REFILL
 #define RT_TREE_REFILL 16             /* tree kernel: free lanes needed before the wave fetches new rays */
 #endif
+#ifndef RT_TREE_BOTH
+#define RT_TREE_BOTH 12               /* tree kernel: lanes that make the minority kind of step worth running too */
+#endif
 #define RT_CHUNK 256u                /* parked-list slots a wave reserves per atomic */
 
 struct QueueCounters {               /* device words, zeroed per launch where noted */
@@ -112,8 +115,17 @@ struct ShadeParams {
     float    half_w, half_h;
 };
 
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 0              /* 0: let the compiler choose the shade kernel's register budget */
+#endif
+#if RT_SHADE_WAVES
+#define RT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES)))
+#else
+#define RT_SHADE_ATTR
+#endif
+
 template <bool FRESH, bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK)
+__global__ void __launch_bounds__(RT_BLOCK) RT_SHADE_ATTR
 rt_shade_kernel(const ShadeParams P)
 {
     rt::Stack stk; stk.base = nullptr; stk.stride = 0;                      /* this kernel walks no tree */
@@ -241,8 +253,17 @@ struct TreeParams {
     uint64_t *stats;
 };
 
+#ifndef RT_TREE_WAVES
+#define RT_TREE_WAVES 0
+#endif
+#if RT_TREE_WAVES
+#define RT_TREE_ATTR __attribute__((amdgpu_waves_per_eu(RT_TREE_WAVES, RT_TREE_WAVES)))
+#else
+#define RT_TREE_ATTR
+#endif
+
 template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK)
+__global__ void __launch_bounds__(RT_BLOCK) RT_TREE_ATTR
 rt_tree_kernel(const TreeParams P)
 {
     extern __shared__ uint32_t lds[];
@@ -259,6 +280,9 @@ rt_tree_kernel(const TreeParams P)
     uint32_t w15 = 0;
     uint32_t in_cur = 0, in_end = 0;
     bool input_done = false;
+    uint32_t cur = RT_ENTRY_NONE;                        /* entry the lane visits next; its record is in ra..rd */
+    rt::u32x4 ra = 0, rb = 0, rc = 0, rd = 0;
+    bool stepped = false;                                /* the lane needs its next record */
 
     auto finish = [&]() {                                /* answer the query: write the hit back */
         uint4 *q = reinterpret_cast<uint4 *>(P.list + (size_t)slot * RT_RECORD_WORDS);
@@ -285,9 +309,8 @@ rt_tree_kernel(const TreeParams P)
             const uint32_t idx = in_cur + rank;
             if (!busy && idx < in_end) {
                 const uint4 *q = reinterpret_cast<const uint4 *>(P.list + (size_t)idx * RT_RECORD_WORDS);
-                const uint4 a = q[0];
+                const uint4 a = q[0], b = q[1], c = q[2], e = q[3];
                 if (a.x & 1u) {
-                    const uint4 b = q[1], c = q[2], e = q[3];
                     slot = idx;
                     any_hit = ((a.x >> 3) & 3u) == (uint32_t)rt::RAY_SHADOW;
                     o = rt::mk(__uint_as_float(a.z), __uint_as_float(a.w), __uint_as_float(b.x));
@@ -295,10 +318,11 @@ rt_tree_kernel(const TreeParams P)
                     h.t = __uint_as_float(c.x); h.type = (int)c.y; h.id = c.z; h.inst = c.w;
                     h.beta = __uint_as_float(e.x); h.gamma = __uint_as_float(e.y); h.material = (int)e.z;
                     w15 = e.w;
-                    tv.inst = (int)(e.w & 0xFFFFu);
-                    busy = true;
+                    tv.inst = (int)(e.w & 0xFFFFu) - 1;  /* walk_next moves on to the instance the ray was parked for */
+                    tv.top = -1; tv.tri_cur = 0; tv.tri_end = 0;
+                    cur = RT_ENTRY_NONE;
+                    busy = true; stepped = true;
                     if (STATS) cn.root_tests--;          /* the shade kernel already counted this root test */
-                    if (!rt::query_scan<STATS, true>(P.S, o, d, h, tv, stk, cn)) finish();
                 }
             }
             in_cur += (uint32_t)__popcll(need);
@@ -308,20 +332,30 @@ rt_tree_kernel(const TreeParams P)
         const unsigned long long working = __ballot(busy);
         if (!working) break;
 
-        /* ---- one tree step of the kind most working lanes want ------------------------ */
-        const bool want_tri = busy && tv.tri_cur < tv.tri_end;
-        const int n_tri = __popcll(__ballot(want_tri)), n_pop = __popcll(working) - n_tri;
-        int r = rt::STEP_MORE;
-        if (n_tri >= n_pop) {
+        /* ---- tree steps: the kind most working lanes want, and the other kind too when at least
+         * RT_TREE_BOTH lanes want it (with the two kinds near balance, running both per
+         * iteration halves the loop overhead per useful lane step) ------------------------ */
+        const bool want_tri = busy && !stepped && tv.tri_cur < tv.tri_end;
+        const bool want_node = busy && !stepped && !want_tri;
+        const int n_tri = __popcll(__ballot(want_tri)), n_node = __popcll(__ballot(want_node));
+        if (n_tri >= n_node || n_tri >= RT_TREE_BOTH) {
             if (STATS) { if (lane == 0) cn.tri_steps++; if (want_tri) cn.tri_lanes++; }
-            if (want_tri) r = rt::query_tri_step<STATS>(P.S, any_hit, h, tv, cn);
-        } else {
-            if (STATS) { if (lane == 0) cn.pop_steps++; if (busy && !want_tri) cn.pop_lanes++; }
-            if (busy && !want_tri) r = rt::query_pop_step<STATS, true>(P.S, h, tv, stk, cn);
+            if (want_tri) {
+                const bool accepted = rt::walk_triangle<STATS>(ra, rb, rc, h, tv, cn);
+                stepped = true;
+                if (accepted && any_hit) { finish(); stepped = false; }
+            }
         }
-        if (r == rt::STEP_QUERY_DONE) finish();
-        else if (r == rt::STEP_INSTANCE_DONE) {
-            if (!(tv.inst < P.S.instance_count) || !rt::query_scan<STATS, true>(P.S, o, d, h, tv, stk, cn)) finish();
+        if (n_node > n_tri || n_node >= RT_TREE_BOTH) {
+            if (STATS) { if (lane == 0) cn.pop_steps++; if (want_node) cn.pop_lanes++; }
+            if (want_node) { rt::walk_node<STATS>(ra, rb, rc, rd, h, tv, stk, cur, cn); stepped = true; }
+        }
+        /* ---- the one place records are requested: every lane that took a step (or a new ray) ---- */
+        if (stepped) {
+            stepped = false;
+            const rt::u32x4 *q = rt::walk_next<STATS>(P.S, o, d, h, tv, stk, cur, cn);
+            if (q) { ra = q[0]; rb = q[1]; rc = q[2]; rd = q[3]; }
+            else finish();
         }
     }
     flush_counters<STATS>(cn, P.stats);

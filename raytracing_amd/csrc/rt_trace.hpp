@@ -457,6 +457,105 @@ __device__ __forceinline__ int query_pop_step(const rt_dev_scene &S, Hit &h, Tra
     return STEP_MORE;
 }
 
+/* ---- the same walk with the next record fetched one step ahead (tree kernel) ----------
+ *
+ * A step of the walk above starts with a dependent chain: stack slot (LDS) -> record address ->
+ * 48 or 64 bytes from L2 -> arithmetic.  Here the entry that will be processed next lives in a
+ * register (`cur`, the would-be top of the stack); after every step walk_next() decides what
+ * the lane processes next and returns that record's address, and the caller requests its 64
+ * bytes at once, at ONE place in its loop, so the latency is covered by whatever the wave does
+ * until the lane's next step.  A leaf entry is opened on the spot (the address is its first
+ * triangle's), so leaves cost no step of their own.  Triangle records are 48 bytes: the
+ * caller's 64-byte request overlaps the next record, and the flattener pads the array by one.
+ * Per ray the sequence of box and triangle tests, and the hit record they see, are unchanged. */
+#define RT_ENTRY_NONE 0xFFFFFFFFu     /* never a valid entry: a leaf's first + count stays below 2^27 */
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+/* address of the record of the lane's next step; nullptr = the query is finished (no instance left) */
+template <bool STATS>
+__device__ __forceinline__ const u32x4 *walk_next(const rt_dev_scene &S, f3 o, f3 d, const Hit &h, Trav &tv,
+                                                  Stack stk, uint32_t &cur, Counters &cn)
+{
+    for (;;) {
+        if (tv.tri_cur < tv.tri_end)
+            return reinterpret_cast<const u32x4 *>(S.tris + tv.tri_base + tv.tri_cur);
+        if (cur == RT_ENTRY_NONE) {
+            if (tv.top < 0) {                            /* this instance is done: on to the next one */
+                tv.inst++;
+                if (!query_scan<STATS, true>(S, o, d, h, tv, stk, cn)) return nullptr;
+            }
+            cur = stk.at(tv.top--);
+        }
+        if (!(cur & RT_ENTRY_LEAF))
+            return reinterpret_cast<const u32x4 *>(S.nodes + tv.node_base + cur);
+        if (STATS) cn.leaf_pops++;
+        tv.tri_cur = cur & RT_ENTRY_FIRST_MASK;
+        tv.tri_end = tv.tri_cur + ((cur >> RT_ENTRY_COUNT_SHIFT) & 15u) + 1u;
+        cur = RT_ENTRY_NONE;
+    }
+}
+
+/* the fetched triangle: src/main.c:449-482; true = accepted as the new closest hit */
+template <bool STATS>
+__device__ __forceinline__ bool walk_triangle(u32x4 fa, u32x4 fb, u32x4 fc, Hit &h, Trav &tv, Counters &cn)
+{
+    const uint32_t j = tv.tri_cur++;
+    if (STATS) cn.tri_tests++;
+    const f3 a = mk(__uint_as_float(fa.x), __uint_as_float(fa.y), __uint_as_float(fa.z));
+    const f3 e1v = mk(__uint_as_float(fa.w), __uint_as_float(fb.x), __uint_as_float(fb.y));
+    const f3 e2v = mk(__uint_as_float(fb.z), __uint_as_float(fb.w), __uint_as_float(fc.x));
+    const f3 n = mk(__uint_as_float(fc.y), __uint_as_float(fc.z), __uint_as_float(fc.w));
+    const f3 oa = sub(tv.mo, a);
+    const float den = dot(tv.mu, n);
+    const float t = -dot(oa, n) / den;
+    if (t < 1e-3f) return false;
+    if (t > h.t) return false;
+    const f3 oau = cross(oa, tv.mu);
+    const float beta = -dot(e2v, oau) / den;
+    const float gamma = dot(e1v, oau) / den;
+    if ((beta < 0) || (beta > 1)) return false;
+    if ((gamma < 0) || (gamma > 1)) return false;
+    if (beta + gamma > 1) return false;
+    h.type = HIT_TRIANGLE; h.t = t; h.id = j; h.inst = (uint32_t)tv.inst;
+    h.beta = beta; h.gamma = gamma; h.material = tv.material;
+    return true;
+}
+
+/* the fetched interior node: src/main.c:397-447; leaves the entry to visit next in cur (or none) */
+template <bool STATS>
+__device__ __forceinline__ void walk_node(u32x4 fa, u32x4 fb, u32x4 fc, u32x4 fd, const Hit &h, Trav &tv, Stack stk,
+                                          uint32_t &cur, Counters &cn)
+{
+    const uint32_t e0 = fd.x, e1 = fd.y;
+    if (fd.z & RT_NODE_PSEUDO) {                         /* chunks of an oversized leaf, in order, no box test */
+        stk.at(++tv.top) = e1;
+        cur = e0;
+        return;
+    }
+    if (STATS) cn.interior_pops++;
+    const f3 lo0 = mk(__uint_as_float(fa.x), __uint_as_float(fa.y), __uint_as_float(fa.z));
+    const f3 hi0 = mk(__uint_as_float(fa.w), __uint_as_float(fb.x), __uint_as_float(fb.y));
+    const f3 lo1 = mk(__uint_as_float(fb.z), __uint_as_float(fb.w), __uint_as_float(fc.x));
+    const f3 hi1 = mk(__uint_as_float(fc.y), __uint_as_float(fc.z), __uint_as_float(fc.w));
+    float n0, l0, n1, l1;
+    if (tv.cached) {
+        slab_cached(lo0, hi0, tv.mo, tv.mu, tv.inv, n0, l0);
+        slab_cached(lo1, hi1, tv.mo, tv.mu, tv.inv, n1, l1);
+    } else {
+        slab(lo0, hi0, tv.mo, tv.mu, n0, l0);
+        slab(lo1, hi1, tv.mo, tv.mu, n1, l1);
+    }
+    const bool h0 = (n0 < l0) && (n0 < h.t);             /* strict: a flat box is never entered */
+    const bool h1 = (n1 < l1) && (n1 < h.t);
+    cur = RT_ENTRY_NONE;
+    if (h0 && h1) {                                      /* nearer child next, farther one stacked; ties: child 0 first */
+        const bool swap = n0 > n1;
+        stk.at(++tv.top) = swap ? e0 : e1;
+        cur = swap ? e1 : e0;
+    } else if (h0) cur = e0;
+    else if (h1) cur = e1;
+}
+
 template <bool STATS>
 __device__ __forceinline__ int query_step(const rt_dev_scene &S, bool any_hit, Hit &h, Trav &tv, Stack stk,
                                           Counters &cn)

@@ -1,0 +1,6 @@
+#!/bin/bash
+# usage: tools/variants.sh lib1.so lib2.so ...   one frame_stats run per library variant (paths relative to the repo root)
+for lib in "$@"; do
+  echo "== $lib"
+  RT_GPU_LIB=$lib timeout -k 10 120 python3 -u tools/frame_stats.py 2>&1 | grep -v amdgpu.ids || exit 1
+done
