@@ -169,14 +169,16 @@ def main():
     # max over ranks of the time, sum over ranks of the rays
     rays = float(st["rays"])
     frames = max(1, st["launches"])
-    shade_ms, tree_ms = st["shade_ms"] / frames, st["tree_ms"] / frames
-    shade_launches, tree_launches = st["rounds"] / frames, max(0.0, st["rounds"] / frames - 1)
+    fresh_ms, tree_ms = st["fresh_ms"] / frames, st["tree_ms"] / frames
+    resume_ms = (st["shade_ms"] - st["fresh_ms"]) / frames
+    resume_launches = max(0.0, st["rounds"] / frames - 1)           # each resume launch follows one tree launch
     if world > 1:
-        t = torch.tensor([elapsed, shade_ms, tree_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, fresh_ms, resume_ms, tree_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         r = torch.tensor([rays], dtype=torch.float64, device="cuda")
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        elapsed, shade_ms, tree_ms, rays = float(t[0]), float(t[1]), float(t[2]), float(r[0])
+        elapsed, fresh_ms, resume_ms, tree_ms, rays = float(t[0]), float(t[1]), float(t[2]), float(t[3]), float(r[0])
+    shade_ms = fresh_ms + resume_ms
     kernel_ms = shade_ms + tree_ms
 
     # algorithmic bytes of ONE frame: the same frame (seed 0) with the detailed counters on, untimed
@@ -189,6 +191,16 @@ def main():
     shade_bytes, tree_bytes = algorithmic_bytes(det, own_pixels)
     abytes = shade_bytes + tree_bytes
     checksum = float(frame.double().sum().item())
+
+    # HBM bytes per frame as counted by the L2's memory-side request counters in a separate
+    # rocprofv3 --pmc run of this command (a bench run cannot collect them itself)
+    traffic, traffic_source = None, None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("workload") == f"{args.scene} {W}x{H} {spp} spp":
+            traffic, traffic_source = tj["bytes_per_frame"], tj["source"]
 
     if rank == 0:
         achieved = abytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -221,18 +233,22 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel": "rt_shade_kernel + rt_tree_kernel, all launches of one frame",
                 "kernel_ms": round(kernel_ms, 3),
                 "kernels": {
                     "rt_shade_kernel": {
-                        "ms_per_frame": round(shade_ms, 3), "launches_per_frame": round(shade_launches, 2),
-                        "avg_launch_ms": round(shade_ms / max(1.0, shade_launches), 4),
+                        "ms_per_frame": round(shade_ms, 3),
+                        "launches_per_frame": round(1 + resume_launches, 2),
+                        "rt_shade_kernel<true, false> (new paths) avg_launch_ms": round(fresh_ms, 3),
+                        "rt_shade_kernel<false, false> (resumed paths) avg_launch_ms":
+                            round(resume_ms / max(1.0, resume_launches), 4),
                         "algorithmic_bytes": int(shade_bytes),
                         "achieved": round(shade_bytes / max(1e-9, shade_ms * 1e-3) / 1e9, 1)},
                     "rt_tree_kernel": {
-                        "ms_per_frame": round(tree_ms, 3), "launches_per_frame": round(tree_launches, 2),
-                        "avg_launch_ms": round(tree_ms / max(1.0, tree_launches), 4),
+                        "ms_per_frame": round(tree_ms, 3), "launches_per_frame": round(resume_launches, 2),
+                        "rt_tree_kernel<false> avg_launch_ms": round(tree_ms / max(1.0, resume_launches), 4),
                         "algorithmic_bytes": int(tree_bytes),
                         "achieved": round(tree_bytes / max(1e-9, tree_ms * 1e-3) / 1e9, 1)},
                 },

@@ -80,8 +80,9 @@ typedef struct rt_gpu_stats {
                              /* all but the first line only with RT_GPU_FLAG_DETAILED_STATS */
     double   kernel_ms;      /* device time of the shade + tree kernels (HIP events on their stream) */
     double   shade_ms, tree_ms;  /* ... and each kernel's share */
+    double   fresh_ms;           /* part of shade_ms spent in the launches that start new paths (first of each batch) */
     uint64_t rounds;         /* shade launches (each but the last followed by a tree launch) */
-    uint64_t overflowed;     /* paths that found the parked list full and walked their tree in the shade kernel */
+    uint64_t overflowed;     /* paths that found the parked list full (always 0: such a call fails) */
     uint32_t launches;       /* render calls x sample batches */
     uint32_t reserved;
 } rt_gpu_stats;

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""profiles/hbm_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
+`bench.py --steps 1 --warmup 0 --no-cpu-baseline`.  That command renders the frame twice: once
+plain, once with the detailed counters (kernel instantiations <..., true>); only the plain
+frame's kernels are summed.  usage: make_traffic_json.py FETCH.csv WRITE.csv TAG"""
+import csv, json, sys
+
+def per_kernel(path, counter):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"]
+        if "rt_" not in name or "true>" in name.replace("<true, false>", ""):
+            continue                                   # not ours, or the detailed-counter frame
+        key = name.split("(")[0].replace("void ", "")
+        out.setdefault(key, []).append(float(r["Counter_Value"]) * 1024.0)
+    return out
+
+fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+kernels = {}
+for k in sorted(set(fetch) | set(write)):
+    f, w = fetch.get(k, []), write.get(k, [])
+    if k == "rt_resolve_kernel":                       # runs once per frame, both frames alike
+        f, w = f[:1], w[:1]
+    kernels[k] = {"launches": max(len(f), len(w)), "fetch_bytes": int(sum(f)), "write_bytes": int(sum(w))}
+total = sum(v["fetch_bytes"] + v["write_bytes"] for v in kernels.values())
+json.dump({
+    "workload": "dog_room 1024x1024 64 spp",
+    "bytes_per_frame": int(total),
+    "source": f"profiles/{sys.argv[3]}_pmc_FETCH_SIZE.csv + profiles/{sys.argv[3]}_pmc_WRITE_SIZE.csv: rocprofv3 --pmc FETCH_SIZE / "
+              "--pmc WRITE_SIZE (separate passes) over one frame, all launches of rt_shade_kernel, rt_tree_kernel and "
+              "rt_resolve_kernel summed, KiB x 1024; raw counter values (the read counter is known to under-report wide "
+              "streaming reads by 2x on gfx950, so the true figure lies between this and this plus fetch_bytes)",
+    "kernels": kernels,
+}, sys.stdout, indent=1)
+print()
