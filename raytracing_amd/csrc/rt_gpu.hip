@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -95,7 +96,8 @@ struct QueueCounters {               /* device words, zeroed per launch where no
     uint32_t unit_next;              /* fresh: next 8x8 pixel block */
     uint32_t in_next;                /* resume / tree: next slot of the input list */
     uint32_t out_reserved;           /* shade: slots reserved in the output list */
-    uint32_t overflow;               /* shade: paths that found the output list full (finished in place) */
+    uint32_t overflow;               /* shade: paths that found the output list full (the call fails) */
+    uint32_t parked;                 /* shade: records actually parked (out_reserved counts whole chunks) */
 };
 
 struct ShadeParams {
@@ -106,6 +108,7 @@ struct ShadeParams {
     const uint32_t *in_list;         /* resume: records parked by the previous round (answered) */
     uint32_t *out_list;              /* records this launch parks */
     uint32_t in_slots, out_capacity;
+    uint32_t chunk;                  /* output slots a wave reserves per atomic (<= RT_CHUNK, multiple of 64) */
     uint32_t width, height;          /* image */
     uint32_t x0, y0, w, h;           /* region */
     uint32_t blocks_x, block_rows;   /* units = 8x8 pixel blocks of this launch */
@@ -115,6 +118,9 @@ struct ShadeParams {
     float    half_w, half_h;
 };
 
+#ifndef RT_SHADE_CLASSES
+#define RT_SHADE_CLASSES 1            /* 1: per iteration only the lanes of the most wanted kind of step run */
+#endif
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 0              /* 0: let the compiler choose the shade kernel's register budget */
 #endif
@@ -148,6 +154,7 @@ rt_shade_kernel(const ShadeParams P)
     uint32_t in_cur = 0, in_end = 0;                    /* resume: reserved input range */
     bool input_done = false;
     uint32_t out_cur = 0, out_end = 0;                  /* reserved output range */
+    uint32_t parked_here = 0;
 
     for (;;) {
         /* ---- 1. give free lanes a path ----------------------------------------- */
@@ -202,8 +209,28 @@ rt_shade_kernel(const ShadeParams P)
         if (!__ballot(has)) break;                       /* nothing in flight and no input left */
 
         /* ---- 2. one shade step ---------------------------------------------------- */
-        if (STATS) { if (lane == 0) cn.shade_steps++; if (has) cn.shade_lanes++; }
-        if (has) {
+        /* Lanes about to do the same kind of step run together: a step's cost is dominated by the
+         * code of its kind (book a surface hit / book a light sample, then a camera, light-sample
+         * or bounce event), and a wave pays for every kind that any active lane takes.  The kind
+         * most lanes want runs; the others keep their state and wait to become the majority
+         * (kinds follow each other in a cycle, so waiting lanes are soon joined). */
+        bool go = has;
+#if RT_SHADE_CLASSES
+        {
+            int kind = 0;                                 /* new path: camera event */
+            if (pm.ray == rt::RAY_SEGMENT) kind = 1;      /* book a surface hit, then usually the first light sample */
+            else if (pm.ev == rt::EV_NEE) kind = (pm.li + 1 < P.S.light_count) ? 2 : 3;   /* next light sample / bounce */
+            const int n0 = __popcll(__ballot(has && kind == 0)), n1 = __popcll(__ballot(has && kind == 1));
+            const int n2 = __popcll(__ballot(has && kind == 2)), n3 = __popcll(__ballot(has && kind == 3));
+            int best = 0, nb = n0;
+            if (n1 > nb) { best = 1; nb = n1; }
+            if (n2 > nb) { best = 2; nb = n2; }
+            if (n3 > nb) { best = 3; nb = n3; }
+            go = has && kind == best;
+        }
+#endif
+        if (STATS) { if (lane == 0) cn.shade_steps++; if (go) cn.shade_lanes++; }
+        if (go) {
             pm.shade_step_park([&]() {
                 const rt::f3 c = pm.path_value();
                 float *dst = P.samples + 3 * (size_t)sample_index;
@@ -222,7 +249,7 @@ rt_shade_kernel(const ShadeParams P)
             uint32_t next_base = 0;
             if (count > room) {                          /* reserve the next chunk; the old one is filled to its end */
                 uint32_t v = 0;
-                if (lane == 0) v = atomicAdd(&P.q->out_reserved, RT_CHUNK);
+                if (lane == 0) v = atomicAdd(&P.q->out_reserved, P.chunk);
                 next_base = __builtin_amdgcn_readfirstlane(v);
             }
             if (has && pm.phase == rt::PH_PARK) {
@@ -235,13 +262,15 @@ rt_shade_kernel(const ShadeParams P)
                 has = false;
                 pm.phase = rt::PH_DEAD;
             }
-            if (count > room) { out_cur = next_base + (count - room); out_end = next_base + RT_CHUNK; }
+            if (count > room) { out_cur = next_base + (count - room); out_end = next_base + P.chunk; }
             else out_cur += count;
+            parked_here += count;
         }
     }
     /* unused tail of the last reserved chunk: mark the slots empty */
     for (uint32_t slot = out_cur + lane; slot < out_end && slot < P.out_capacity; slot += 64)
         P.out_list[(size_t)slot * RT_RECORD_WORDS] = 0u;
+    if (lane == 0 && parked_here) atomicAdd(&P.q->parked, parked_here);
     flush_counters<STATS>(cn, P.stats);
 }
 
@@ -357,6 +386,54 @@ rt_tree_kernel(const TreeParams P)
             if (q) { ra = q[0]; rb = q[1]; rc = q[2]; rd = q[3]; }
             else finish();
         }
+    }
+    flush_counters<STATS>(cn, P.stats);
+}
+
+/* ---- the last few paths of a launch: parked records walked to their end in place -------
+ * Rounds of shade and tree launches stop paying when a handful of paths is left (a launch has a
+ * floor of some 50 us and ends with its slowest ray).  This kernel takes the parked, not yet
+ * answered records and runs each path to its end with the in-wave scheduler: shade, node and
+ * triangle steps by ballot, trees walked by the lane itself. */
+struct FinishParams {
+    rt_dev_scene S;
+    const uint32_t *list; uint32_t slots;
+    float *samples; uint64_t *stats; QueueCounters *q;
+    uint32_t seed0, seed1;
+    int max_segments;
+    float half_w, half_h;
+};
+
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK)
+rt_finish_kernel(const FinishParams P)
+{
+    extern __shared__ uint32_t lds[];
+    rt::Stack stk; stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK;
+    rt::Counters cn; memset(&cn, 0, sizeof(cn));
+    const uint32_t lane = threadIdx.x & 63;
+    rt::PathMachine<rt::CounterRng, STATS> pm(P.S, stk, cn);
+    pm.half_w = P.half_w; pm.half_h = P.half_h; pm.max_segments = P.max_segments;
+    pm.rng.seed0 = P.seed0; pm.rng.seed1 = P.seed1;
+    for (;;) {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&P.q->in_next, 64u);
+        const uint32_t base = __builtin_amdgcn_readfirstlane(v);
+        if (base >= P.slots) break;
+        const uint32_t idx = base + lane;
+        uint32_t sample_index = 0;
+        pm.phase = rt::PH_DEAD;
+        if (idx < P.slots && pm.load_record(P.list + (size_t)idx * RT_RECORD_WORDS, sample_index)) {
+            pm.tv.inst = (int)(P.list[(size_t)idx * RT_RECORD_WORDS + 15] & 0xFFFFu);   /* instance the ray was parked for */
+            pm.phase = rt::PH_SCAN;
+            if (STATS) cn.root_tests--;                  /* counted when the ray was parked */
+        }
+        pm.run(RT_SHADE_WEIGHT, [&]() {
+            const rt::f3 c = pm.path_value();
+            float *dst = P.samples + 3 * (size_t)sample_index;
+            dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
+            pm.phase = rt::PH_DEAD;
+        });
     }
     flush_counters<STATS>(cn, P.stats);
 }
@@ -550,7 +627,7 @@ struct rt_gpu_scene {
     float *d_samples = nullptr; uint64_t scratch_bytes = 0;   /* per-sample values between shading and resolve */
     uint32_t *d_parked[2] = {nullptr, nullptr}; uint64_t parked_records = 0;   /* paths in transit, ping-pong */
     QueueCounters *d_queue = nullptr;
-    uint32_t shade_blocks = 0, tree_blocks = 0;               /* persistent grid sizes */
+    uint32_t shade_blocks = 0, tree_blocks = 0, finish_blocks = 0;   /* persistent grid sizes */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tree_timers;
     double tree_ms = 0.0, fresh_ms = 0.0;
     uint64_t overflowed = 0, rounds = 0;
@@ -680,6 +757,9 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
             int per_cu_shade = 0, per_cu_tree = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, rt_shade_kernel<true, false>, RT_BLOCK, 0) != hipSuccess || per_cu_shade < 1) per_cu_shade = 1;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tree, rt_tree_kernel<false>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_tree < 1) per_cu_tree = 1;
+            int per_cu_finish = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_finish, rt_finish_kernel<false>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_finish < 1) per_cu_finish = 1;
+            s->finish_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_finish);
             s->shade_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_shade);
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
         }
@@ -862,22 +942,31 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     const uint32_t shade_grid = s->shade_blocks, tree_grid = s->tree_blocks;
     const uint32_t resolve_grid = (uint32_t)((units * 64 + RT_BLOCK - 1) / RT_BLOCK);
 
+    const bool trace_rounds = getenv("RT_GPU_TRACE_ROUNDS") != nullptr;
+    uint32_t finish_below = 262144;                     /* parked records at or below which one launch finishes the paths */
+    if (const char *e = getenv("RT_GPU_FINISH_BELOW")) finish_below = (uint32_t)atoll(e);
+    auto trace_t = std::chrono::steady_clock::now();
     for (uint32_t first = 0; first < spp; first += (uint32_t)per_launch) {
         P.first_sample = first;
         P.launch_spp = (uint32_t)(spp - first < per_launch ? spp - first : per_launch);
         uint32_t *list_in = s->d_parked[0], *list_out = s->d_parked[1];
-        uint32_t in_slots = 0;
+        uint32_t in_slots = 0, in_records = 0;
         for (uint32_t round = 0;; round++) {
             RT_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(QueueCounters), stream));
             P.in_list = list_in; P.in_slots = in_slots; P.out_list = list_out;
+            /* few records per wave: reserve output slots in smaller chunks (less padding to skip later)
+             * and launch no more workgroups than there are 64-record portions of input */
+            P.chunk = (round == 0 || in_records >= (4u << 20)) ? RT_CHUNK : 64u;
+            uint32_t grid = shade_grid;
+            if (round > 0 && (in_slots + 255) / 256 < grid) grid = (in_slots + 255) / 256;
             hipEvent_t e0 = take_event(s), e1 = take_event(s);
             if (e0 && e1) RT_HIP(hipEventRecord(e0, stream));
             if (round == 0) {
-                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<true, true>), dim3(shade_grid), dim3(RT_BLOCK), 0, stream, P);
-                else hipLaunchKernelGGL((rt_shade_kernel<true, false>), dim3(shade_grid), dim3(RT_BLOCK), 0, stream, P);
+                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<true, true>), dim3(grid), dim3(RT_BLOCK), 0, stream, P);
+                else hipLaunchKernelGGL((rt_shade_kernel<true, false>), dim3(grid), dim3(RT_BLOCK), 0, stream, P);
             } else {
-                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<false, true>), dim3(shade_grid), dim3(RT_BLOCK), 0, stream, P);
-                else hipLaunchKernelGGL((rt_shade_kernel<false, false>), dim3(shade_grid), dim3(RT_BLOCK), 0, stream, P);
+                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<false, true>), dim3(grid), dim3(RT_BLOCK), 0, stream, P);
+                else hipLaunchKernelGGL((rt_shade_kernel<false, false>), dim3(grid), dim3(RT_BLOCK), 0, stream, P);
             }
             RT_HIP(hipGetLastError());
             if (e0 && e1) { RT_HIP(hipEventRecord(e1, stream)); s->timers.push_back({e0, e1, round == 0}); }
@@ -888,21 +977,48 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
             s->rounds++;
             if (qc.overflow) return fail(RT_GPU_ERR_DEVICE, "parked-path list overflow (" + std::to_string(qc.overflow) + " paths lost)");
             uint32_t parked = qc.out_reserved < capacity ? qc.out_reserved : (uint32_t)capacity;
-            if (getenv("RT_GPU_TRACE_ROUNDS")) fprintf(stderr, "round %u: in %u slots -> parked %u slots, overflow %u\n", round, in_slots, parked, qc.overflow);
+            if (trace_rounds) {
+                const auto now = std::chrono::steady_clock::now();
+                float shade_ms = 0.0f, tree_ms = 0.0f;
+                if (!s->timers.empty()) (void)hipEventElapsedTime(&shade_ms, s->timers.back().first, s->timers.back().second);
+                if (round > 0 && !s->tree_timers.empty()) (void)hipEventElapsedTime(&tree_ms, s->tree_timers.back().first, s->tree_timers.back().second);
+                fprintf(stderr, "round %u: in %u records (%u slots) -> parked %u records (%u slots); tree %.3f ms, shade %.3f ms, host %.3f ms since the previous read-back\n",
+                        round, in_records, in_slots, qc.parked, parked, tree_ms, shade_ms, std::chrono::duration<double, std::milli>(now - trace_t).count());
+                trace_t = now;
+            }
             if (parked == 0) break;
+            RT_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(QueueCounters), stream));
+            if (qc.parked <= finish_below) {
+                /* a handful of paths left: one launch walks them to their end */
+                FinishParams F;
+                memset(&F, 0, sizeof(F));
+                F.S = P.S; F.list = list_out; F.slots = parked; F.samples = P.samples; F.stats = s->d_stats; F.q = s->d_queue;
+                F.seed0 = P.seed0; F.seed1 = P.seed1; F.max_segments = P.max_segments; F.half_w = P.half_w; F.half_h = P.half_h;
+                uint32_t fgrid = (parked + 255) / 256;
+                if (fgrid > s->finish_blocks) fgrid = s->finish_blocks;
+                hipEvent_t f0 = take_event(s), f1 = take_event(s);
+                if (f0 && f1) RT_HIP(hipEventRecord(f0, stream));
+                if (detailed) hipLaunchKernelGGL(rt_finish_kernel<true>, dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
+                else hipLaunchKernelGGL(rt_finish_kernel<false>, dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
+                RT_HIP(hipGetLastError());
+                if (f0 && f1) { RT_HIP(hipEventRecord(f1, stream)); s->timers.push_back({f0, f1, false}); }
+                s->rounds++;
+                break;
+            }
             /* answer the parked queries, then resume those paths */
             TreeParams T;
             memset(&T, 0, sizeof(T));
             T.S = P.S; T.list = list_out; T.slots = parked; T.q = s->d_queue; T.stats = s->d_stats;
-            RT_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(QueueCounters), stream));
+            uint32_t tgrid = tree_grid;
+            if ((parked + 255) / 256 < tgrid) tgrid = (parked + 255) / 256;
             hipEvent_t t0 = take_event(s), t1 = take_event(s);
             if (t0 && t1) RT_HIP(hipEventRecord(t0, stream));
-            if (detailed) hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(tree_grid), dim3(RT_BLOCK), lds, stream, T);
-            else hipLaunchKernelGGL(rt_tree_kernel<false>, dim3(tree_grid), dim3(RT_BLOCK), lds, stream, T);
+            if (detailed) hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(tgrid), dim3(RT_BLOCK), lds, stream, T);
+            else hipLaunchKernelGGL(rt_tree_kernel<false>, dim3(tgrid), dim3(RT_BLOCK), lds, stream, T);
             RT_HIP(hipGetLastError());
             if (t0 && t1) { RT_HIP(hipEventRecord(t1, stream)); s->tree_timers.emplace_back(t0, t1); }
             uint32_t *tmp = list_in; list_in = list_out; list_out = tmp;
-            in_slots = parked;
+            in_slots = parked; in_records = qc.parked;
         }
         R.launch_spp = P.launch_spp;
         R.start_from_pixels = (accumulate || first > 0) ? 1 : 0;

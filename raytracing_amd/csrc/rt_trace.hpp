@@ -87,6 +87,10 @@ __device__ __forceinline__ void threefry2x32_20(uint32_t k0, uint32_t k1, uint32
 {
     const uint32_t k2 = 0x1BD11BDAu ^ k0 ^ k1;
     uint32_t x0 = c0 + k0, x1 = c1 + k1;
+#if defined(RT_ABLATE_RNG)       /* timing experiment only: wrong bits */
+    x0 += x1; x1 = __builtin_rotateleft32(x1, 13); x1 ^= x0; x0 += k2; x0 ^= x0 >> 15; x0 *= 0x2c1b3c6du; x1 += x0; x1 ^= x1 >> 13;
+    o0 = x0; o1 = x1; return;
+#endif
 #define RT_TF_ROUND(r) x0 += x1; x1 = __builtin_rotateleft32(x1, r); x1 ^= x0;
     RT_TF_ROUND(13) RT_TF_ROUND(15) RT_TF_ROUND(26) RT_TF_ROUND(6)
     x0 += k1; x1 += k2 + 1u;
@@ -818,9 +822,17 @@ struct PathMachine {
         rng.uniform2(u0, u1);
         if (STATS) cn.rng_draws++;
         float sn, cs;
+#if defined(RT_ABLATE_TRIG)      /* timing experiment only: wrong bits */
+        sn = __sinf((float)(2.0 * RT_PI_D * (double)u0)); cs = __cosf((float)(2.0 * RT_PI_D * (double)u0));
+#else
         rt_sincosf((float)(2.0 * RT_PI_D * (double)u0), &sn, &cs);
+#endif
         float arg;
-        if (ev == EV_CAMERA) arg = -2 * rt_logf(u1);                      /* Box-Muller radius^2, src/math.c:230 */
+#if defined(RT_ABLATE_TRIG)
+        if (ev == EV_CAMERA) arg = -2 * __logf(u1);
+#else
+        if (ev == EV_CAMERA) arg = -2 * rt_logf(u1);
+#endif                      /* Box-Muller radius^2, src/math.c:230 */
         else if (ev == EV_NEE) arg = 2 * u1 - u1 * u1;                    /* src/main.c:555 */
         else arg = 1 - u1;                                                /* src/main.c:696 */
         float ring = __builtin_sqrtf(arg);
