@@ -278,9 +278,6 @@ int rt_flatten_scene(const rt_scene *scene, rt_flat_scene &out)
         di.material = (int32_t)sm.material_id;
         out.instances.push_back(di);
     }
-    /* the tree kernel requests 64 bytes per 48-byte triangle record: one record of padding keeps
-     * the request for the last triangle inside the array */
-    if (!out.tris.empty()) { rt_dev_tri pad; memset(&pad, 0, sizeof(pad)); out.tris.push_back(pad); }
     return 0;
 }
 

@@ -285,6 +285,11 @@ struct TreeParams {
 #ifndef RT_TREE_WAVES
 #define RT_TREE_WAVES 0
 #endif
+#ifndef RT_TREE_LEAF_MIN
+#define RT_TREE_LEAF_MIN 16           /* rays waiting at a leaf that make a leaf pass worth running beside node steps */
+#endif
+#define RT_TREE_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * 256u * 4u)   /* bytes per workgroup for the leaf passes */
+#define RT_LEAF_WORDS_PER_WAVE 256u   /* LDS words per wave for the leaf passes: 64 keys (2 words) + 64 x (beta, gamma) */
 #if RT_TREE_WAVES
 #define RT_TREE_ATTR __attribute__((amdgpu_waves_per_eu(RT_TREE_WAVES, RT_TREE_WAVES)))
 #else
@@ -300,6 +305,10 @@ rt_tree_kernel(const TreeParams P)
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    /* after the stacks: per wave 64 keys (8 bytes) and 64 barycentric pairs for the leaf passes */
+    uint32_t *leaf_area = lds + (size_t)RT_BLOCK * P.S.stack_cap + (threadIdx.x >> 6) * RT_LEAF_WORDS_PER_WAVE;
+    unsigned long long *leaf_best = reinterpret_cast<unsigned long long *>(leaf_area);
+    float *leaf_bary = reinterpret_cast<float *>(leaf_area + 128);
 
     bool busy = false, any_hit = false;
     uint32_t slot = 0;
@@ -347,7 +356,7 @@ rt_tree_kernel(const TreeParams P)
                     h.t = __uint_as_float(c.x); h.type = (int)c.y; h.id = c.z; h.inst = c.w;
                     h.beta = __uint_as_float(e.x); h.gamma = __uint_as_float(e.y); h.material = (int)e.z;
                     w15 = e.w;
-                    tv.inst = (int)(e.w & 0xFFFFu) - 1;  /* walk_next moves on to the instance the ray was parked for */
+                    tv.inst = (int)(e.w & 0xFFFFu) - 1;  /* walk_advance moves on to the instance the ray was parked for */
                     tv.top = -1; tv.tri_cur = 0; tv.tri_end = 0;
                     cur = RT_ENTRY_NONE;
                     busy = true; stepped = true;
@@ -361,30 +370,120 @@ rt_tree_kernel(const TreeParams P)
         const unsigned long long working = __ballot(busy);
         if (!working) break;
 
-        /* ---- tree steps: the kind most working lanes want, and the other kind too when at least
-         * RT_TREE_BOTH lanes want it (with the two kinds near balance, running both per
-         * iteration halves the loop overhead per useful lane step) ------------------------ */
+        /* ---- node steps by the lane that owns the ray; leaves by the whole wave ------------- */
         const bool want_tri = busy && !stepped && tv.tri_cur < tv.tri_end;
         const bool want_node = busy && !stepped && !want_tri;
-        const int n_tri = __popcll(__ballot(want_tri)), n_node = __popcll(__ballot(want_node));
-        if (n_tri >= n_node || n_tri >= RT_TREE_BOTH) {
-            if (STATS) { if (lane == 0) cn.tri_steps++; if (want_tri) cn.tri_lanes++; }
+        const unsigned long long tri_mask = __ballot(want_tri);
+        const int n_tri = __popcll(tri_mask), n_node = __popcll(__ballot(want_node));
+        const bool run_node = n_node > 0 && (n_node >= n_tri || n_node >= RT_TREE_BOTH);
+        const bool run_leaf = n_tri > 0 && (n_tri >= RT_TREE_LEAF_MIN || !run_node);
+        if (run_node) {
+            if (STATS) { if (lane == 0) cn.pop_steps++; if (want_node) cn.pop_lanes++; }
+            if (want_node) { rt::walk_node<STATS>(ra, rb, rc, rd, h, tv, stk, cur, cn); stepped = true; }
+        }
+        if (run_leaf) {
+            /* pairs are numbered ray by ray: ray of lane l owns pairs first..first+count-1 */
+            const uint32_t count = want_tri ? tv.tri_end - tv.tri_cur : 0u;
+            uint32_t incl = count;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+                if (lane >= (uint32_t)off) incl += v;
+            }
+            const uint32_t first = incl - count;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            /* owners packed to the low lanes (a permutation of the wave), for the search below */
+            const uint32_t dest = want_tri ? (uint32_t)__popcll(tri_mask & lanes_below)
+                                           : (uint32_t)n_tri + (uint32_t)__popcll(~tri_mask & lanes_below);
+            const uint32_t packed_first = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest * 4u), want_tri ? (int)first : -1);
+            const uint32_t packed_lane = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest * 4u), (int)lane);
+            unsigned long long *best = leaf_best + lane;     /* this lane's slot as an owner */
+            /* closest-hit rays: key = bits of t << 32 | (0xFFFFFFFE - place): smallest t, ties to the later triangle.
+             * any-hit rays stop at the first accepted triangle: key = place << 32 | bits of t.  0 = walk one by one. */
+            if (want_tri) *best = (h.t != h.t) ? 0ull
+                                : any_hit ? ~0ull : (((unsigned long long)__float_as_uint(h.t) << 32) | 0xFFFFFFFFull);
+            const uint32_t tri_first = (tv.tri_base + tv.tri_cur) | (any_hit ? 0x80000000u : 0u);
+            for (uint32_t base = 0; base < total; base += 64u) {
+                const uint32_t k = base + lane;
+                uint32_t pos = 0;                            /* last packed owner whose first pair is <= k */
+                for (uint32_t step = 32u; step; step >>= 1) {
+                    const uint32_t probe = pos + step;
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(probe * 4u), (int)packed_first);
+                    if (v <= k) pos = probe;
+                }
+                const uint32_t owner = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos * 4u), (int)packed_lane);
+                const int from = (int)(owner * 4u);
+                const uint32_t own_first = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)first);
+                const uint32_t own_word = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)tri_first);
+                const uint32_t own_tri = own_word & 0x7FFFFFFFu;
+                const bool own_any = (own_word >> 31) != 0u;
+                rt::f3 mo, mu;
+                mo.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mo.x)));
+                mo.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mo.y)));
+                mo.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mo.z)));
+                mu.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mu.x)));
+                mu.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mu.y)));
+                mu.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mu.z)));
+                const float entry_t = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(h.t)));
+                if (STATS) { if (lane == 0) cn.tri_steps++; if (k < total) cn.tri_lanes++; }
+                if (k < total) {
+                    const uint32_t place = k - own_first;    /* position in the leaf's remaining triangles */
+                    const rt::u32x4 *q = reinterpret_cast<const rt::u32x4 *>(P.S.tris + own_tri + place);
+                    const rt::u32x4 fa = q[0], fb = q[1], fc = q[2];
+                    float t, beta, gamma;
+                    if (STATS && !own_any) cn.tri_tests++;   /* an any-hit ray counts its tests when it reads its result */
+                    const int verdict = rt::leaf_pair(fa, fb, fc, mo, mu, entry_t, t, beta, gamma);
+                    if (verdict != rt::PAIR_REJECTED) {
+                        unsigned long long *slot_best = leaf_best + owner;
+                        const unsigned long long key = verdict == rt::PAIR_UNORDERED ? 0ull
+                            : own_any ? (((unsigned long long)place << 32) | (unsigned long long)__float_as_uint(t))
+                                      : (((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(0xFFFFFFFEu - place));
+                        atomicMin(slot_best, key);
+                        /* a minimum with all-ones changes nothing and returns the slot as an LDS operation, in order behind
+                         * the wave's updates above */
+                        if (key && atomicMin(slot_best, ~0ull) == key) {                 /* best so far: leave the barycentrics */
+                            leaf_bary[2 * owner] = beta; leaf_bary[2 * owner + 1] = gamma;
+                        }
+                    }
+                }
+            }
             if (want_tri) {
-                const bool accepted = rt::walk_triangle<STATS>(ra, rb, rc, h, tv, cn);
+                const unsigned long long key = atomicMin(best, ~0ull);
+                bool accepted = false;
+                if (key == 0ull) {                           /* unordered distance somewhere: the host's one-by-one walk */
+                    while (tv.tri_cur < tv.tri_end) {
+                        const int r = rt::query_tri_step<STATS>(P.S, any_hit, h, tv, cn);
+                        if (STATS && !any_hit) cn.tri_tests--;   /* counted by the pass above */
+                        if (r == rt::STEP_QUERY_DONE) { accepted = true; break; }   /* only an any-hit ray needs to know */
+                    }
+                } else if (any_hit) {
+                    const uint32_t count_here = tv.tri_end - tv.tri_cur;
+                    if (key != ~0ull) {
+                        const uint32_t place = (uint32_t)(key >> 32);
+                        h.type = rt::HIT_TRIANGLE; h.t = __uint_as_float((uint32_t)key);
+                        h.id = tv.tri_cur + place; h.inst = (uint32_t)tv.inst;
+                        h.beta = leaf_bary[2 * lane]; h.gamma = leaf_bary[2 * lane + 1]; h.material = tv.material;
+                        accepted = true;
+                        if (STATS) cn.tri_tests += place + 1u;   /* the host stops at this triangle */
+                    } else if (STATS) cn.tri_tests += count_here;
+                } else if ((uint32_t)key != 0xFFFFFFFFu) {
+                    const uint32_t place = 0xFFFFFFFEu - (uint32_t)key;
+                    h.type = rt::HIT_TRIANGLE; h.t = __uint_as_float((uint32_t)(key >> 32));
+                    h.id = tv.tri_cur + place; h.inst = (uint32_t)tv.inst;
+                    h.beta = leaf_bary[2 * lane]; h.gamma = leaf_bary[2 * lane + 1]; h.material = tv.material;
+                    accepted = true;
+                }
+                tv.tri_cur = tv.tri_end;
                 stepped = true;
                 if (accepted && any_hit) { finish(); stepped = false; }
             }
         }
-        if (n_node > n_tri || n_node >= RT_TREE_BOTH) {
-            if (STATS) { if (lane == 0) cn.pop_steps++; if (want_node) cn.pop_lanes++; }
-            if (want_node) { rt::walk_node<STATS>(ra, rb, rc, rd, h, tv, stk, cur, cn); stepped = true; }
-        }
         /* ---- the one place records are requested: every lane that took a step (or a new ray) ---- */
         if (stepped) {
             stepped = false;
-            const rt::u32x4 *q = rt::walk_next<STATS>(P.S, o, d, h, tv, stk, cur, cn);
-            if (q) { ra = q[0]; rb = q[1]; rc = q[2]; rd = q[3]; }
-            else finish();
+            const rt::u32x4 *q = nullptr;
+            const int next = rt::walk_advance<STATS>(P.S, o, d, h, tv, stk, cur, q, cn);
+            if (next == rt::NEXT_NODE) { ra = q[0]; rb = q[1]; rc = q[2]; rd = q[3]; }
+            else if (next == rt::NEXT_DONE) finish();
         }
     }
     flush_counters<STATS>(cn, P.stats);
@@ -718,7 +817,7 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
         if (hipGetDevice(&s->device) != hipSuccess) { rc = fail(RT_GPU_ERR_DEVICE, "hipGetDevice failed"); break; }
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) { rc = fail(RT_GPU_ERR_DEVICE, "hipGetDeviceProperties failed"); break; }
-        size_t lds_need = (size_t)RT_BLOCK * flat.stack_cap * 4 + 1024 + 64;
+        size_t lds_need = (size_t)RT_BLOCK * flat.stack_cap * 4 + RT_TREE_EXTRA_LDS + 64;
         if (lds_need > prop.sharedMemPerBlock) {
             rc = fail(RT_GPU_ERR_SCENE, "box tree too deep for the LDS traversal stack (" + std::to_string(flat.stack_cap) + " levels)");
             break;
@@ -756,7 +855,7 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
             const size_t lds_bytes = (size_t)RT_BLOCK * flat.stack_cap * 4;
             int per_cu_shade = 0, per_cu_tree = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, rt_shade_kernel<true, false>, RT_BLOCK, 0) != hipSuccess || per_cu_shade < 1) per_cu_shade = 1;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tree, rt_tree_kernel<false>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_tree < 1) per_cu_tree = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tree, rt_tree_kernel<false>, RT_BLOCK, lds_bytes + RT_TREE_EXTRA_LDS) != hipSuccess || per_cu_tree < 1) per_cu_tree = 1;
             int per_cu_finish = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_finish, rt_finish_kernel<false>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_finish < 1) per_cu_finish = 1;
             s->finish_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_finish);
@@ -1013,8 +1112,8 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
             if ((parked + 255) / 256 < tgrid) tgrid = (parked + 255) / 256;
             hipEvent_t t0 = take_event(s), t1 = take_event(s);
             if (t0 && t1) RT_HIP(hipEventRecord(t0, stream));
-            if (detailed) hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(tgrid), dim3(RT_BLOCK), lds, stream, T);
-            else hipLaunchKernelGGL(rt_tree_kernel<false>, dim3(tgrid), dim3(RT_BLOCK), lds, stream, T);
+            if (detailed) hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(tgrid), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, stream, T);
+            else hipLaunchKernelGGL(rt_tree_kernel<false>, dim3(tgrid), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, stream, T);
             RT_HIP(hipGetLastError());
             if (t0 && t1) { RT_HIP(hipEventRecord(t1, stream)); s->tree_timers.emplace_back(t0, t1); }
             uint32_t *tmp = list_in; list_in = list_out; list_out = tmp;

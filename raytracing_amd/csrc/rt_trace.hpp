@@ -461,69 +461,18 @@ __device__ __forceinline__ int query_pop_step(const rt_dev_scene &S, Hit &h, Tra
     return STEP_MORE;
 }
 
-/* ---- the same walk with the next record fetched one step ahead (tree kernel) ----------
+/* ---- the same walk with the next node fetched one step ahead (tree kernel) -------------
  *
  * A step of the walk above starts with a dependent chain: stack slot (LDS) -> record address ->
- * 48 or 64 bytes from L2 -> arithmetic.  Here the entry that will be processed next lives in a
- * register (`cur`, the would-be top of the stack); after every step walk_next() decides what
- * the lane processes next and returns that record's address, and the caller requests its 64
- * bytes at once, at ONE place in its loop, so the latency is covered by whatever the wave does
- * until the lane's next step.  A leaf entry is opened on the spot (the address is its first
- * triangle's), so leaves cost no step of their own.  Triangle records are 48 bytes: the
- * caller's 64-byte request overlaps the next record, and the flattener pads the array by one.
- * Per ray the sequence of box and triangle tests, and the hit record they see, are unchanged. */
+ * 64 bytes from L2 -> arithmetic.  Here the entry that will be processed next lives in a
+ * register (`cur`, the would-be top of the stack); after every step walk_advance() decides what
+ * the lane does next: for an interior node it returns the record's address and the caller
+ * requests the 64 bytes at once, at ONE place in its loop, so the latency is covered by whatever
+ * the wave does until the lane's next step; a leaf entry is opened on the spot and waits for the
+ * wave's next leaf pass.  Per ray the sequence of box tests and the hit record they see are
+ * unchanged. */
 #define RT_ENTRY_NONE 0xFFFFFFFFu     /* never a valid entry: a leaf's first + count stays below 2^27 */
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-/* address of the record of the lane's next step; nullptr = the query is finished (no instance left) */
-template <bool STATS>
-__device__ __forceinline__ const u32x4 *walk_next(const rt_dev_scene &S, f3 o, f3 d, const Hit &h, Trav &tv,
-                                                  Stack stk, uint32_t &cur, Counters &cn)
-{
-    for (;;) {
-        if (tv.tri_cur < tv.tri_end)
-            return reinterpret_cast<const u32x4 *>(S.tris + tv.tri_base + tv.tri_cur);
-        if (cur == RT_ENTRY_NONE) {
-            if (tv.top < 0) {                            /* this instance is done: on to the next one */
-                tv.inst++;
-                if (!query_scan<STATS, true>(S, o, d, h, tv, stk, cn)) return nullptr;
-            }
-            cur = stk.at(tv.top--);
-        }
-        if (!(cur & RT_ENTRY_LEAF))
-            return reinterpret_cast<const u32x4 *>(S.nodes + tv.node_base + cur);
-        if (STATS) cn.leaf_pops++;
-        tv.tri_cur = cur & RT_ENTRY_FIRST_MASK;
-        tv.tri_end = tv.tri_cur + ((cur >> RT_ENTRY_COUNT_SHIFT) & 15u) + 1u;
-        cur = RT_ENTRY_NONE;
-    }
-}
-
-/* the fetched triangle: src/main.c:449-482; true = accepted as the new closest hit */
-template <bool STATS>
-__device__ __forceinline__ bool walk_triangle(u32x4 fa, u32x4 fb, u32x4 fc, Hit &h, Trav &tv, Counters &cn)
-{
-    const uint32_t j = tv.tri_cur++;
-    if (STATS) cn.tri_tests++;
-    const f3 a = mk(__uint_as_float(fa.x), __uint_as_float(fa.y), __uint_as_float(fa.z));
-    const f3 e1v = mk(__uint_as_float(fa.w), __uint_as_float(fb.x), __uint_as_float(fb.y));
-    const f3 e2v = mk(__uint_as_float(fb.z), __uint_as_float(fb.w), __uint_as_float(fc.x));
-    const f3 n = mk(__uint_as_float(fc.y), __uint_as_float(fc.z), __uint_as_float(fc.w));
-    const f3 oa = sub(tv.mo, a);
-    const float den = dot(tv.mu, n);
-    const float t = -dot(oa, n) / den;
-    if (t < 1e-3f) return false;
-    if (t > h.t) return false;
-    const f3 oau = cross(oa, tv.mu);
-    const float beta = -dot(e2v, oau) / den;
-    const float gamma = dot(e1v, oau) / den;
-    if ((beta < 0) || (beta > 1)) return false;
-    if ((gamma < 0) || (gamma > 1)) return false;
-    if (beta + gamma > 1) return false;
-    h.type = HIT_TRIANGLE; h.t = t; h.id = j; h.inst = (uint32_t)tv.inst;
-    h.beta = beta; h.gamma = gamma; h.material = tv.material;
-    return true;
-}
 
 /* the fetched interior node: src/main.c:397-447; leaves the entry to visit next in cur (or none) */
 template <bool STATS>
@@ -558,6 +507,67 @@ __device__ __forceinline__ void walk_node(u32x4 fa, u32x4 fb, u32x4 fc, u32x4 fd
         cur = swap ? e1 : e0;
     } else if (h0) cur = e0;
     else if (h1) cur = e1;
+}
+
+/* ---- leaves tested by the whole wave --------------------------------------------------
+ * A leaf holds up to 16 triangles that the host tests one after the other for one ray
+ * (src/main.c:449-482).  A lane doing that keeps 16 steps busy while lanes in the node part of
+ * their walk wait.  Here the rays that have reached a leaf pool their (ray, triangle) pairs and
+ * the wave tests 64 pairs per step.  The sequential rule "accept when 1e-3 <= t <= the closest
+ * hit so far, barycentrics in range; equal t replaces" reduces to: among the valid pairs of a
+ * ray with t <= its entry distance, the smallest t wins and ties go to the later triangle.
+ * That is an integer minimum over keys (bits of t) << 32 | (0xFFFFFFFE - position in the
+ * leaf), taken with 64-bit LDS atomics; t >= 1e-3 > 0, so float order is unsigned order.
+ * The one case the rule does not cover, a NaN distance (the host then accepts whatever comes
+ * next), sends the ray back to the one-by-one test: key 0 marks it. */
+enum : int { PAIR_REJECTED = 0, PAIR_VALID = 1, PAIR_UNORDERED = 2 };
+
+/* one (ray, triangle) pair against the distance the ray entered the leaf with */
+__device__ __forceinline__ int leaf_pair(u32x4 fa, u32x4 fb, u32x4 fc, f3 mo, f3 mu, float entry_t,
+                                         float &t, float &beta, float &gamma)
+{
+    const f3 a = mk(__uint_as_float(fa.x), __uint_as_float(fa.y), __uint_as_float(fa.z));
+    const f3 e1v = mk(__uint_as_float(fa.w), __uint_as_float(fb.x), __uint_as_float(fb.y));
+    const f3 e2v = mk(__uint_as_float(fb.z), __uint_as_float(fb.w), __uint_as_float(fc.x));
+    const f3 n = mk(__uint_as_float(fc.y), __uint_as_float(fc.z), __uint_as_float(fc.w));
+    const f3 oa = sub(mo, a);
+    const float den = dot(mu, n);
+    t = -dot(oa, n) / den;
+    if (t < 1e-3f) return PAIR_REJECTED;
+    if (t > entry_t) return PAIR_REJECTED;
+    const f3 oau = cross(oa, mu);
+    beta = -dot(e2v, oau) / den;
+    gamma = dot(e1v, oau) / den;
+    if ((beta < 0) || (beta > 1)) return PAIR_REJECTED;
+    if ((gamma < 0) || (gamma > 1)) return PAIR_REJECTED;
+    if (beta + gamma > 1) return PAIR_REJECTED;
+    return t != t ? PAIR_UNORDERED : PAIR_VALID;
+}
+
+/* what the lane does after a step: NEXT_NODE = visit the interior node whose record is at
+ * `addr`; NEXT_LEAF = tv.tri_cur..tv.tri_end wait for the wave's next leaf pass; NEXT_DONE = no
+ * instance left, the query is answered */
+enum : int { NEXT_DONE = 0, NEXT_NODE = 1, NEXT_LEAF = 2 };
+template <bool STATS>
+__device__ __forceinline__ int walk_advance(const rt_dev_scene &S, f3 o, f3 d, const Hit &h, Trav &tv, Stack stk,
+                                            uint32_t &cur, const u32x4 *&addr, Counters &cn)
+{
+    if (cur == RT_ENTRY_NONE) {
+        if (tv.top < 0) {                                /* this instance is done: on to the next one */
+            tv.inst++;
+            if (!query_scan<STATS, true>(S, o, d, h, tv, stk, cn)) return NEXT_DONE;
+        }
+        cur = stk.at(tv.top--);
+    }
+    if (!(cur & RT_ENTRY_LEAF)) {
+        addr = reinterpret_cast<const u32x4 *>(S.nodes + tv.node_base + cur);
+        return NEXT_NODE;
+    }
+    if (STATS) cn.leaf_pops++;
+    tv.tri_cur = cur & RT_ENTRY_FIRST_MASK;
+    tv.tri_end = tv.tri_cur + ((cur >> RT_ENTRY_COUNT_SHIFT) & 15u) + 1u;
+    cur = RT_ENTRY_NONE;
+    return NEXT_LEAF;
 }
 
 template <bool STATS>
