@@ -122,7 +122,7 @@ struct ShadeParams {
 #define RT_SHADE_CLASSES 1            /* 1: per iteration only the lanes of the most wanted kind of step run */
 #endif
 #ifndef RT_SHADE_WAVES
-#define RT_SHADE_WAVES 0              /* 0: let the compiler choose the shade kernel's register budget */
+#define RT_SHADE_WAVES 4              /* waves per SIMD the shade kernel is compiled for (0: compiler's choice) */
 #endif
 #if RT_SHADE_WAVES
 #define RT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES)))

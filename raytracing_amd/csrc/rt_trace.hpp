@@ -296,33 +296,51 @@ __device__ __forceinline__ bool query_begin(const rt_dev_scene &S, f3 o, f3 d, f
     const RT_CMEM rt_dev_light *lights = cmem(S.lights);
     const RT_CMEM rt_dev_sphere *spheres = cmem(S.spheres);
     const RT_CMEM rt_dev_plane *planes = cmem(S.planes);
-    for (int i = 0; i < S.light_count; i++) {
-        const RT_CMEM rt_dev_light &l = lights[i];
-        float t;
-        if (STATS) cn.light_tests++;
-        if (ball(ld3(l.c), l.radius, o, d, h.t, t, h.entered)) {
-            h.type = HIT_LIGHT; h.id = (uint32_t)i; h.t = t;
-            if (any_hit) return true;
+    /* each table entry is fetched (scalar loads) one iteration ahead of its use, so the fetch of
+     * entry i+1 overlaps the arithmetic on entry i */
+    if (S.light_count > 0) {
+        f3 c = ld3(lights[0].c); float radius = lights[0].radius;
+        for (int i = 0; i < S.light_count; i++) {
+            const int nx = i + 1 < S.light_count ? i + 1 : i;
+            const f3 c_next = ld3(lights[nx].c); const float radius_next = lights[nx].radius;
+            float t;
+            if (STATS) cn.light_tests++;
+            if (ball(c, radius, o, d, h.t, t, h.entered)) {
+                h.type = HIT_LIGHT; h.id = (uint32_t)i; h.t = t;
+                if (any_hit) return true;
+            }
+            c = c_next; radius = radius_next;
         }
     }
-    for (int i = 0; i < S.sphere_count; i++) {
-        const RT_CMEM rt_dev_sphere &s = spheres[i];
-        float t;
-        if (STATS) cn.sphere_tests++;
-        if (ball(ld3(s.c), s.radius, o, d, h.t, t, h.entered)) {
-            h.type = HIT_SPHERE; h.id = (uint32_t)i; h.t = t; h.material = s.material;
-            if (any_hit) return true;
+    if (S.sphere_count > 0) {
+        f3 c = ld3(spheres[0].c); float radius = spheres[0].radius; int material = spheres[0].material;
+        for (int i = 0; i < S.sphere_count; i++) {
+            const int nx = i + 1 < S.sphere_count ? i + 1 : i;
+            const f3 c_next = ld3(spheres[nx].c); const float radius_next = spheres[nx].radius;
+            const int material_next = spheres[nx].material;
+            float t;
+            if (STATS) cn.sphere_tests++;
+            if (ball(c, radius, o, d, h.t, t, h.entered)) {
+                h.type = HIT_SPHERE; h.id = (uint32_t)i; h.t = t; h.material = material;
+                if (any_hit) return true;
+            }
+            c = c_next; radius = radius_next; material = material_next;
         }
     }
-    for (int i = 0; i < S.plane_count; i++) {                        /* src/main.c:355-369 */
-        const RT_CMEM rt_dev_plane &p = planes[i];
-        f3 n = ld3(p.n);
-        if (STATS) cn.plane_tests++;
-        float t = (p.d - dot(o, n)) / dot(d, n);
-        if (t < 1e-3f) continue;
-        if (t > h.t) continue;
-        h.type = HIT_PLANE; h.id = (uint32_t)i; h.t = t; h.material = p.material;
-        if (any_hit) return true;
+    if (S.plane_count > 0) {                                         /* src/main.c:355-369 */
+        f3 n = ld3(planes[0].n); float pd = planes[0].d; int material = planes[0].material;
+        for (int i = 0; i < S.plane_count; i++) {
+            const int nx = i + 1 < S.plane_count ? i + 1 : i;
+            const f3 n_next = ld3(planes[nx].n); const float pd_next = planes[nx].d;
+            const int material_next = planes[nx].material;
+            if (STATS) cn.plane_tests++;
+            const float t = (pd - dot(o, n)) / dot(d, n);
+            if (!(t < 1e-3f) && !(t > h.t)) {
+                h.type = HIT_PLANE; h.id = (uint32_t)i; h.t = t; h.material = material;
+                if (any_hit) return true;
+            }
+            n = n_next; pd = pd_next; material = material_next;
+        }
     }
     return S.instance_count == 0;
 }
