@@ -141,9 +141,16 @@ int rt_gpu_render_jobs(rt_gpu_scene *scene, const rt_job *jobs, uint32_t job_cou
                        const rt_gpu_options *options);
 
 /* Batched find_ray_hit (src/main.c:264): out[i] = closest hit of rays[i] within
- * max_distance, every field as the reference fills it. */
+ * max_distance, every field as the reference fills it.  Runs the render path's own kernels
+ * (primitive and root-box tests as the shade kernel makes them, rt_tree_kernel for the mesh
+ * trees), so it probes exactly the code that renders. */
 int rt_gpu_find_ray_hit(rt_gpu_scene *scene, const rt_ray *rays, uint32_t ray_count,
                         float max_distance, rt_ray_result *out);
+
+/* The same query (src/main.c:264) by a plain one-lane-per-ray walk in the reference's loop
+ * order: an independent second implementation to check the one above against. */
+int rt_gpu_find_ray_hit_serial(rt_gpu_scene *scene, const rt_ray *rays, uint32_t ray_count,
+                               float max_distance, rt_ray_result *out);
 
 /* Gamma + truncating 8-bit quantiser of save_image (src/main.c:73-82) on host
  * float pixels; rgb receives 3 bytes per pixel. */

@@ -636,6 +636,24 @@ rt_render_jobs_kernel(const JobParams P)
 }
 
 /* ---- batched closest-hit probe, output in the host's Ray_Result layout ----- */
+/* one Ray_Result (src/math.h:148-168 layout, 72 bytes) */
+__device__ __forceinline__ void write_ray_result(uint8_t *dst, const rt::Hit &h, const rt::Surface &sf)
+{
+    uint32_t *w = reinterpret_cast<uint32_t *>(dst);
+    float *f = reinterpret_cast<float *>(w);
+    const bool hit = h.type != rt::HIT_NONE;
+    w[0] = hit ? 1u : 0u;
+    w[1] = hit ? (uint32_t)h.type : 0u;
+    w[2] = h.id;
+    w[3] = h.type == rt::HIT_TRIANGLE ? h.inst : 0u;
+    f[4] = sf.p.x; f[5] = sf.p.y; f[6] = sf.p.z;
+    f[7] = sf.n.x; f[8] = sf.n.y; f[9] = sf.n.z;
+    f[10] = h.t; f[11] = sf.alpha; f[12] = h.beta; f[13] = h.gamma;
+    f[14] = sf.u; f[15] = sf.v;
+    w[16] = h.entered ? 1u : 0u;
+    w[17] = (uint32_t)h.material;
+}
+
 struct HitParams {
     rt_dev_scene S;
     const float *rays;          /* 6 floats per ray */
@@ -658,19 +676,58 @@ rt_find_hit_kernel(const HitParams P)
         rt::closest_hit<true>(P.S, o, d, P.max_distance, false, stk, h, cn);
         rt::Surface sf;
         rt::surface_of<true>(P.S, o, d, h, sf, cn);
-        uint32_t *w = reinterpret_cast<uint32_t *>(P.results + 72 * (size_t)i);
-        float *f = reinterpret_cast<float *>(w);
-        const bool hit = h.type != rt::HIT_NONE;
-        w[0] = hit ? 1u : 0u;
-        w[1] = hit ? (uint32_t)h.type : 0u;
-        w[2] = h.id;
-        w[3] = h.type == rt::HIT_TRIANGLE ? h.inst : 0u;
-        f[4] = sf.p.x; f[5] = sf.p.y; f[6] = sf.p.z;
-        f[7] = sf.n.x; f[8] = sf.n.y; f[9] = sf.n.z;
-        f[10] = h.t; f[11] = sf.alpha; f[12] = h.beta; f[13] = h.gamma;
-        f[14] = sf.u; f[15] = sf.v;
-        w[16] = h.entered ? 1u : 0u;
-        w[17] = (uint32_t)h.material;
+        write_ray_result(P.results + 72 * (size_t)i, h, sf);
+    }
+    flush_counters<true>(cn, P.stats);
+}
+
+/* ---- closest-hit probes through the render kernels' own machinery: the ray's scene primitives
+ * and root-box test as the shade kernel does them, a parked record for rt_tree_kernel when the
+ * ray enters an instance, then the surface attributes.  Word 0 of the record: bit 0 = parked,
+ * bit 7 = entered flag of the sphere tests; the tree kernel leaves it alone. */
+struct HitPackParams {
+    rt_dev_scene S;
+    const float *rays; uint32_t *list; uint64_t *stats;
+    uint32_t count; float max_distance;
+};
+
+__global__ void __launch_bounds__(RT_BLOCK)
+rt_hit_pack_kernel(const HitPackParams P)
+{
+    rt::Counters cn; memset(&cn, 0, sizeof(cn));
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i < P.count) {
+        const rt::f3 o = rt::ld3(P.rays + 6 * i), d = rt::ld3(P.rays + 6 * i + 3);
+        rt::Hit h;
+        int park = -1;
+        if (!rt::query_begin<true>(P.S, o, d, P.max_distance, false, h, cn)) park = rt::query_probe<true>(P.S, o, d, h, 0, cn);
+        uint4 *q = reinterpret_cast<uint4 *>(P.list + (size_t)i * RT_RECORD_WORDS);
+        const uint32_t flags = (park >= 0 ? 1u : 0u) | ((uint32_t)rt::RAY_SEGMENT << 3) | (h.entered ? 0x80u : 0u);
+        q[0] = make_uint4(flags, 0u, __float_as_uint(o.x), __float_as_uint(o.y));
+        q[1] = make_uint4(__float_as_uint(o.z), __float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z));
+        q[2] = make_uint4(__float_as_uint(h.t), (uint32_t)h.type, h.id, h.inst);
+        q[3] = make_uint4(__float_as_uint(h.beta), __float_as_uint(h.gamma), (uint32_t)h.material, (uint32_t)(park >= 0 ? park : 0));
+    }
+    flush_counters<true>(cn, P.stats);
+}
+
+__global__ void __launch_bounds__(RT_BLOCK)
+rt_hit_unpack_kernel(const HitPackParams P, uint8_t *results)
+{
+    rt::Counters cn; memset(&cn, 0, sizeof(cn));
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i < P.count) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(P.list + (size_t)i * RT_RECORD_WORDS);
+        const uint4 a = q[0], b = q[1], c = q[2], e = q[3];
+        const rt::f3 o = rt::mk(__uint_as_float(a.z), __uint_as_float(a.w), __uint_as_float(b.x));
+        const rt::f3 d = rt::mk(__uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+        rt::Hit h;
+        h.t = __uint_as_float(c.x); h.type = (int)c.y; h.id = c.z; h.inst = c.w;
+        h.beta = __uint_as_float(e.x); h.gamma = __uint_as_float(e.y); h.material = (int)e.z;
+        h.entered = (a.x & 0x80u) != 0u;
+        rt::Surface sf;
+        rt::surface_of<true>(P.S, o, d, h, sf, cn);
+        write_ray_result(results + 72 * (size_t)i, h, sf);
     }
     flush_counters<true>(cn, P.stats);
 }
@@ -1244,36 +1301,74 @@ int rt_gpu_render_jobs(rt_gpu_scene *s, const rt_job *jobs, uint32_t job_count, 
     return RT_GPU_OK;
 }
 
-int rt_gpu_find_ray_hit(rt_gpu_scene *s, const rt_ray *rays, uint32_t ray_count, float max_distance,
-                        rt_ray_result *out)
+static int find_ray_hit(rt_gpu_scene *s, const rt_ray *rays, uint32_t ray_count, float max_distance,
+                        rt_ray_result *out, bool serial)
 {
     if (!s || !rays || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_find_ray_hit: NULL argument");
     if (!ray_count) return RT_GPU_OK;
     static_assert(sizeof(rt_ray) == 24 && sizeof(rt_ray_result) == 72, "host record layout");
     RT_HIP(hipSetDevice(s->device));
-    float *d_rays = nullptr; uint8_t *d_res = nullptr;
+    float *d_rays = nullptr; uint8_t *d_res = nullptr; uint32_t *d_list = nullptr;
     if (hipMalloc(reinterpret_cast<void **>(&d_rays), (size_t)ray_count * 24) != hipSuccess)
         return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the ray table");
     if (hipMalloc(reinterpret_cast<void **>(&d_res), (size_t)ray_count * 72) != hipSuccess) {
         (void)hipFree(d_rays);
         return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the result table");
     }
+    if (!serial && hipMalloc(reinterpret_cast<void **>(&d_list), (size_t)ray_count * RT_RECORD_WORDS * 4) != hipSuccess) {
+        (void)hipFree(d_rays); (void)hipFree(d_res);
+        return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the ray records");
+    }
+    const uint32_t grid = (ray_count + RT_BLOCK - 1) / RT_BLOCK;
+    const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
     hipError_t e = hipMemcpy(d_rays, rays, (size_t)ray_count * 24, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d_res, 0, (size_t)ray_count * 72);
-    if (e == hipSuccess) {
+    if (e == hipSuccess && serial) {
         HitParams P;
         memset(&P, 0, sizeof(P));
         P.S = s->dev; P.rays = d_rays; P.results = d_res; P.stats = s->d_stats;
         P.count = ray_count; P.max_distance = max_distance;
-        hipLaunchKernelGGL(rt_find_hit_kernel, dim3((ray_count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK),
-                           (size_t)RT_BLOCK * s->dev.stack_cap * 4, nullptr, P);
+        hipLaunchKernelGGL(rt_find_hit_kernel, dim3(grid), dim3(RT_BLOCK), lds, nullptr, P);
         e = hipGetLastError();
+    } else if (e == hipSuccess) {
+        HitPackParams P;
+        memset(&P, 0, sizeof(P));
+        P.S = s->dev; P.rays = d_rays; P.list = d_list; P.stats = s->d_stats;
+        P.count = ray_count; P.max_distance = max_distance;
+        hipLaunchKernelGGL(rt_hit_pack_kernel, dim3(grid), dim3(RT_BLOCK), 0, nullptr, P);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemsetAsync(s->d_queue, 0, sizeof(QueueCounters), nullptr);
+        if (e == hipSuccess) {
+            TreeParams T;
+            memset(&T, 0, sizeof(T));
+            T.S = s->dev; T.list = d_list; T.slots = ray_count; T.q = s->d_queue; T.stats = s->d_stats;
+            uint32_t tgrid = s->tree_blocks < grid ? s->tree_blocks : grid;
+            hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(tgrid), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, nullptr, T);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(rt_hit_unpack_kernel, dim3(grid), dim3(RT_BLOCK), 0, nullptr, P, d_res);
+            e = hipGetLastError();
+        }
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(out, d_res, (size_t)ray_count * 72, hipMemcpyDeviceToHost);
     (void)hipFree(d_rays); (void)hipFree(d_res);
+    if (d_list) (void)hipFree(d_list);
     if (e != hipSuccess) return fail(RT_GPU_ERR_DEVICE, std::string("closest-hit probe: ") + hipGetErrorString(e));
     return RT_GPU_OK;
+}
+
+int rt_gpu_find_ray_hit(rt_gpu_scene *s, const rt_ray *rays, uint32_t ray_count, float max_distance,
+                        rt_ray_result *out)
+{
+    return find_ray_hit(s, rays, ray_count, max_distance, out, false);
+}
+
+int rt_gpu_find_ray_hit_serial(rt_gpu_scene *s, const rt_ray *rays, uint32_t ray_count, float max_distance,
+                               rt_ray_result *out)
+{
+    return find_ray_hit(s, rays, ray_count, max_distance, out, true);
 }
 
 /* src/main.c:73-82 on the host: min(c,1) (a NaN becomes 1), powf(c, 1/2.2f), *255, truncate */

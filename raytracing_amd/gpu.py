@@ -21,7 +21,7 @@ FLAG_COMPACT_BANDS = 4
 EXPORTS = [
     "rt_gpu_device_count", "rt_gpu_last_error", "rt_gpu_scene_create", "rt_gpu_scene_destroy",
     "rt_gpu_scene_set_camera", "rt_gpu_render_region", "rt_gpu_render_region_device",
-    "rt_gpu_normalize_device", "rt_gpu_render_jobs", "rt_gpu_find_ray_hit", "rt_gpu_quantize",
+    "rt_gpu_normalize_device", "rt_gpu_render_jobs", "rt_gpu_find_ray_hit", "rt_gpu_find_ray_hit_serial", "rt_gpu_quantize",
     "rt_gpu_get_stats", "rt_gpu_reset_stats", "rt_gpu_eval_math",
 ]
 
@@ -85,6 +85,7 @@ def lib():
         L.rt_gpu_render_jobs.argtypes = [C.c_void_p, C.POINTER(T.Job), C.c_uint32, C.POINTER(Options)]
         L.rt_gpu_find_ray_hit.argtypes = [C.c_void_p, C.POINTER(T.Ray), C.c_uint32, C.c_float,
                                           C.POINTER(T.RayResult)]
+        L.rt_gpu_find_ray_hit_serial.argtypes = L.rt_gpu_find_ray_hit.argtypes
         L.rt_gpu_quantize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.rt_gpu_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.rt_gpu_reset_stats.argtypes = [C.c_void_p]
@@ -139,13 +140,14 @@ class GpuScene:
         _check(lib().rt_gpu_render_jobs(self._h, arr, len(jobs),
                                         C.byref(options) if options is not None else None))
 
-    def find_ray_hit(self, rays, max_distance):
-        """rays: (n, 6) float32 -> ctypes array of RayResult."""
+    def find_ray_hit(self, rays, max_distance, serial=False):
+        """rays: (n, 6) float32 -> ctypes array of RayResult.  serial=True: the one-lane-per-ray
+        walk instead of the render path's kernels (same results, a second implementation)."""
         rays = np.ascontiguousarray(rays, dtype=np.float32)
         n = len(rays)
         out = (T.RayResult * n)()
-        _check(lib().rt_gpu_find_ray_hit(self._h, C.cast(rays.ctypes.data, C.POINTER(T.Ray)), n,
-                                         max_distance, out))
+        call = lib().rt_gpu_find_ray_hit_serial if serial else lib().rt_gpu_find_ray_hit
+        _check(call(self._h, C.cast(rays.ctypes.data, C.POINTER(T.Ray)), n, max_distance, out))
         return out
 
     def stats(self):

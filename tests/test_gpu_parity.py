@@ -82,17 +82,20 @@ def test_device_math_equals_host_math(golden):
 
 # ---------------------------------------------------------------- find_ray_hit
 
+@pytest.mark.parametrize("serial", [False, True], ids=["render_kernels", "serial_walk"])
 @pytest.mark.parametrize("name", ["deux_spheres", "sphere_room", "dog_room", "three_dogs"])
 @pytest.mark.parametrize("tag,maxd", [("inf", FLT_MAX), ("d60", 60.0)])
-def test_find_ray_hit_matches_reference_vectors(golden, gpu_scenes, name, tag, maxd):
-    """rt_gpu_find_ray_hit against the compiled reference's find_ray_hit (src/main.c:264), all
-    fields of Ray_Result; traversal counters against the oracle's for the same rays."""
+def test_find_ray_hit_matches_reference_vectors(golden, gpu_scenes, name, tag, maxd, serial):
+    """rt_gpu_find_ray_hit (the render path's kernels: shade-side primitive tests, rt_tree_kernel
+    with its wave-wide leaf passes) and rt_gpu_find_ray_hit_serial against the compiled
+    reference's find_ray_hit (src/main.c:264), all fields of Ray_Result; traversal counters
+    against the oracle's for the same rays."""
     from test_oracle_golden import check_results
     g = golden("hit_kat")
     sh, gs = gpu_scenes(name)
     rays = g[name + "_rays"]
     gs.reset_stats()
-    res = gs.find_ray_hit(rays, maxd)
+    res = gs.find_ray_hit(rays, maxd, serial=serial)
     check_results(res, g, f"{name}_{tag}", len(rays))
     st = L.Stats()
     tmp = T.RayResult()
@@ -102,6 +105,103 @@ def test_find_ray_hit_matches_reference_vectors(golden, gpu_scenes, name, tag, m
     got = gs.stats()
     for key in ("rays", "root_tests", "interior_pops", "leaf_pops", "tri_tests", "tri_hits"):
         assert got[key] == getattr(st, key), key
+
+
+def _result_fields(res):
+    import sys
+    sys.path.insert(0, L.ORACLE_DIR)
+    from make_golden import results_to_arrays
+    return results_to_arrays(res)
+
+
+@pytest.mark.parametrize("name", ["dog_room", "three_dogs"])
+def test_find_ray_hit_many_rays_and_awkward_rays(gpu_scenes, name):
+    """Both device implementations against the oracle on rays the fixtures do not hold: a large
+    random batch (waves full of rays in different parts of the tree), rays that graze boxes,
+    axis-parallel rays (zero direction components: infinite slab quotients), rays from inside
+    the mesh, very short and very long maximum distances.  Every word of Ray_Result."""
+    sh, gs = gpu_scenes(name)
+    rng = np.random.default_rng(7)
+    n = 6000
+    o = rng.uniform(-9.0, 9.0, (n, 3)).astype(np.float32)
+    o[:, 1] = np.abs(o[:, 1])
+    target = rng.uniform(-3.0, 3.0, (n, 3)).astype(np.float32)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    axis = np.zeros((600, 3), np.float32)
+    axis[np.arange(600), np.arange(600) % 3] = np.where(np.arange(600) % 2, 1.0, -1.0)
+    o_axis = rng.uniform(-4.0, 4.0, (600, 3)).astype(np.float32)
+    inside_o = rng.uniform(-0.5, 0.5, (1000, 3)).astype(np.float32) + np.array([0, 1.5, 0], np.float32)
+    inside_d = rng.standard_normal((1000, 3)).astype(np.float32)
+    inside_d /= np.linalg.norm(inside_d, axis=1, keepdims=True).astype(np.float32)
+    rays = np.concatenate([np.hstack([o, d]), np.hstack([o_axis, axis]), np.hstack([inside_o, inside_d])]).astype(np.float32)
+    for maxd in (FLT_MAX, 7.5, 0.01):
+        want = (T.RayResult * len(rays))()
+        for i in range(len(rays)):
+            ray = T.Ray(T.Vec3f(*rays[i, :3].tolist()), T.Vec3f(*rays[i, 3:].tolist()))
+            L.oracle().orc_find_ray_hit(sh.ptr, C.byref(ray), maxd, C.byref(want[i]), None)
+        want_f = _result_fields(want)
+        for serial in (False, True):
+            got_f = _result_fields(gs.find_ray_hit(rays, maxd, serial=serial))
+            for f, w in want_f.items():
+                same = L.same_bits(got_f[f], w) if w.dtype == np.float32 else (got_f[f] == w)
+                assert same.all(), (serial, maxd, f, np.nonzero(~same.reshape(len(rays), -1).all(axis=1))[0][:5])
+        if maxd == FLT_MAX:
+            assert (want_f["object_type"][want_f["hit"] != 0] == 3).sum() > 500    # plenty of triangle hits among them
+
+
+def test_find_ray_hit_rays_inside_a_triangle_plane(gpu_scenes):
+    """A ray lying in the plane of a triangle divides 0 by 0: the distance is NaN, no comparison
+    rejects it and the host accepts the triangle and, from then on, every later one whose
+    barycentrics do not fail a comparison (src/main.c:449-482).  The wave-wide leaf pass cannot
+    order a NaN, so such rays must take the one-by-one walk; a second instance behind the first
+    is entered with a NaN closest distance.  Same fields as the oracle (NaNs compared as NaNs:
+    the sign of an invalid-operation NaN differs between x86 and the GPU)."""
+    cam = scenes.room_camera()
+    k = 2       # k x k quads in one plane (the mesh builder maps OBJ z to the mesh's y: the plane is y = 0) ...
+    p = np.array([[0.0, 0.0, 0.0]] + [[x, y, 0.0] for y in range(k + 1) for x in range(k + 1)] +
+                 [[0.5, 0.25, -1.0], [1.5, 0.25, 1.0], [1.0, 1.75, 1.0]], np.float32)      # entry 0: the parser's dummy
+    tri = []
+    for y in range(k):
+        for x in range(k):
+            a, b, c, d = y * (k + 1) + x + 1, y * (k + 1) + x + 2, (y + 1) * (k + 1) + x + 2, (y + 1) * (k + 1) + x + 1
+            tri += [[a, b, c], [a, c, d]]
+    m = (k + 1) * (k + 1)
+    tri.insert(3, [m + 1, m + 2, m + 3])            # ... and one triangle across it, so that the boxes are not flat
+    ids = np.array([[[v, 0, 1] for v in t] for t in tri], np.uint32).reshape(-1, 3)
+    mesh = host.mesh_from_obj_arrays(p, np.zeros((1, 2), np.float32), np.array([[0, 0, 0], [0, 0, 1]], np.float32),
+                                     ids, np.full(len(tri), 3, np.uint32))
+    sh = scenes.SceneHandle("flat", cam, scenes.room_materials(), [], [], [],
+                            [scenes.instance(mesh, (0.0, 0.0, 8.0), 0), scenes.instance(mesh, (16.0, 0.0, 8.0), 0)],
+                            keep=[mesh])
+    gs = gpu.GpuScene(sh)
+    rng = np.random.default_rng(3)
+    n = 512
+    o = np.zeros((n, 3), np.float32)
+    o[:, 0] = rng.integers(-40, 0, n) / 8.0         # left of the first instance, exactly representable
+    o[:, 1] = 0.0                                   # in the plane of both instances
+    o[:, 2] = 8.0 + rng.integers(1, 16, n) / 8.0
+    d = np.zeros((n, 3), np.float32)
+    d[:, 0] = 1.0
+    d[:, 2] = rng.integers(-8, 9, n) / 64.0
+    off = rng.random(n) < 0.25                      # a quarter of the rays leave the plane: ordinary hits or misses
+    d[off, 1] = rng.uniform(-0.2, 0.2, int(off.sum())).astype(np.float32)
+    rays = np.hstack([o, d]).astype(np.float32)
+    want = (T.RayResult * n)()
+    for i in range(n):
+        ray = T.Ray(T.Vec3f(*rays[i, :3].tolist()), T.Vec3f(*rays[i, 3:].tolist()))
+        L.oracle().orc_find_ray_hit(sh.ptr, C.byref(ray), FLT_MAX, C.byref(want[i]), None)
+    want_f = _result_fields(want)
+    assert np.isnan(want_f["t_min"]).sum() > n // 4                  # the case is really there
+    for serial in (False, True):
+        got_f = _result_fields(gs.find_ray_hit(rays, FLT_MAX, serial=serial))
+        for f, w in want_f.items():
+            if w.dtype == np.float32:
+                same = L.same_bits(got_f[f], w) | (np.isnan(got_f[f]) & np.isnan(w))
+            else:
+                same = got_f[f] == w
+            assert same.all(), (serial, f, np.nonzero(~same.reshape(n, -1).all(axis=1))[0][:5])
+    gs.close()
 
 
 # ---------------------------------------------------------------- the render loop, counter generator
