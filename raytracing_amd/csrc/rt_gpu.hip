@@ -283,7 +283,8 @@ struct TreeParams {
 };
 
 #ifndef RT_TREE_WAVES
-#define RT_TREE_WAVES 0
+#define RT_TREE_WAVES 5               /* waves per SIMD the tree kernel is compiled for (0: compiler's choice); its LDS
+                                       * (stacks + leaf-pass slots, 30 KB per workgroup for a 26-level tree) allows 5 */
 #endif
 #ifndef RT_TREE_LEAF_MIN
 #define RT_TREE_LEAF_MIN 16           /* rays waiting at a leaf that make a leaf pass worth running beside node steps */
@@ -377,10 +378,8 @@ rt_tree_kernel(const TreeParams P)
         const int n_tri = __popcll(tri_mask), n_node = __popcll(__ballot(want_node));
         const bool run_node = n_node > 0 && (n_node >= n_tri || n_node >= RT_TREE_BOTH);
         const bool run_leaf = n_tri > 0 && (n_tri >= RT_TREE_LEAF_MIN || !run_node);
-        if (run_node) {
-            if (STATS) { if (lane == 0) cn.pop_steps++; if (want_node) cn.pop_lanes++; }
-            if (want_node) { rt::walk_node<STATS>(ra, rb, rc, rd, h, tv, stk, cur, cn); stepped = true; }
-        }
+        /* the leaf pass goes first: the node records requested at the end of the previous iteration
+         * have its whole duration to arrive */
         if (run_leaf) {
             /* pairs are numbered ray by ray: ray of lane l owns pairs first..first+count-1 */
             const uint32_t count = want_tri ? tv.tri_end - tv.tri_cur : 0u;
@@ -476,6 +475,10 @@ rt_tree_kernel(const TreeParams P)
                 stepped = true;
                 if (accepted && any_hit) { finish(); stepped = false; }
             }
+        }
+        if (run_node) {
+            if (STATS) { if (lane == 0) cn.pop_steps++; if (want_node) cn.pop_lanes++; }
+            if (want_node) { rt::walk_node<STATS>(ra, rb, rc, rd, h, tv, stk, cur, cn); stepped = true; }
         }
         /* ---- the one place records are requested: every lane that took a step (or a new ray) ---- */
         if (stepped) {
