@@ -118,6 +118,9 @@ struct ShadeParams {
     float    half_w, half_h;
 };
 
+#ifndef RT_PORTION_SPP
+#define RT_PORTION_SPP 8u             /* samples per pixel in one portion of fresh work (x 64 pixels) */
+#endif
 #ifndef RT_SHADE_CLASSES
 #define RT_SHADE_CLASSES 1            /* 1: per iteration only the lanes of the most wanted kind of step run */
 #endif
@@ -147,9 +150,11 @@ rt_shade_kernel(const ShadeParams P)
     uint32_t sample_index = 0;
 
     /* wave-uniform cursors */
+    /* fresh work comes in portions of one 8x8 pixel block x RT_PORTION_SPP samples: small enough to
+     * keep thousands of waves evenly loaded on a fraction of a frame */
     const uint32_t units = P.blocks_x * P.block_rows;
-    const uint32_t unit_items = 64u * P.launch_spp;
-    uint32_t unit = 0, item_next = unit_items;          /* fresh: current unit and next item in it */
+    const uint32_t parts = (P.launch_spp + RT_PORTION_SPP - 1u) / RT_PORTION_SPP;
+    uint32_t unit = 0, item_next = 0, unit_items = 0;   /* fresh: current block, next item and end of the portion */
     uint32_t bx = 0, by = 0;
     uint32_t in_cur = 0, in_end = 0;                    /* resume: reserved input range */
     bool input_done = false;
@@ -162,12 +167,15 @@ rt_shade_kernel(const ShadeParams P)
             const unsigned long long need = __ballot(!has);
             if (!need) break;
             if (FRESH) {
-                if (item_next >= unit_items) {           /* next 8x8 block */
+                if (item_next >= unit_items) {           /* next portion */
                     uint32_t u = 0;
                     if (lane == 0) u = atomicAdd(&P.q->unit_next, 1u);
-                    unit = __builtin_amdgcn_readfirstlane(u);
-                    if (unit >= units) { input_done = true; break; }
-                    item_next = 0;
+                    u = __builtin_amdgcn_readfirstlane(u);
+                    if (u >= units * parts) { input_done = true; break; }
+                    unit = u / parts;
+                    const uint32_t first_spp = (u % parts) * RT_PORTION_SPP;
+                    const uint32_t end_spp = first_spp + RT_PORTION_SPP < P.launch_spp ? first_spp + RT_PORTION_SPP : P.launch_spp;
+                    item_next = 64u * first_spp; unit_items = 64u * end_spp;
                     bx = unit % P.blocks_x; by = unit / P.blocks_x;
                     if (P.band_blocks) {
                         uint32_t k = by / P.band_blocks, in = by % P.band_blocks;
