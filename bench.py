@@ -12,6 +12,14 @@ bands into a packed buffer and one all-gather over xGMI assembles the frame on e
 The frame is the same whatever N is (the generator is keyed by pixel and sample), so this is
 strong scaling of a fixed frame.
 
+Frames are independent, and the end of a frame is latency-bound (a few long paths, a few
+thousand rays per launch), so --frames-in-flight of them (default 3) are rendered concurrently,
+each on its own stream with its own device work lists: the tail of frame i overlaps the
+machine-filling first launch of frame i+1 and, with N > 1, the all-gather of frame i overlaps
+rendering.  Every timed frame is complete (rendered, gathered, assembled) inside the timed
+region; ms_per_step is elapsed / K, not the latency of one frame (--frames-in-flight 1 gives
+that).
+
 Rank 0 prints one JSON line.  A frame is rendered by two kernels that alternate: rt_shade_kernel
 (path bookkeeping, sampling, the scene's lights/spheres/planes, instance root boxes) and
 rt_tree_kernel (mesh tree walks for the rays the shade kernel parked), a few dozen launches per
@@ -103,6 +111,8 @@ def main():
     ap.add_argument("--scene", default="dog_room")
     ap.add_argument("--max-segments", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="frames rendered concurrently (each with its own stream and device work lists)")
     args = ap.parse_args()
 
     import torch
@@ -125,29 +135,61 @@ def main():
     W, H, spp = args.width, args.height, args.spp
     band = multi_gpu.BAND_ROWS
     sh = scenes.CONFIGS[args.scene]()
-    g = gpu.GpuScene(sh)                               # flatten + upload: outside the timed region
-    stream = torch.cuda.current_stream().cuda_stream
+    in_flight = max(1, args.frames_in_flight)
 
+    # One "lane" per frame in flight: its own resident scene (with its own work lists on the device),
+    # stream and output buffers.  Frames are rendered by worker threads (the C call releases the GIL),
+    # so the latency-bound last rounds of frame i overlap the first, machine-filling launch of frame
+    # i+1; collectives stay on this thread, in frame order.
+    class Lane:
+        pass
+    lanes = []
+    for k in range(in_flight):
+        ln = Lane()
+        ln.g = gpu.GpuScene(sh)                        # flatten + upload: outside the timed region
+        ln.stream = torch.cuda.Stream()
+        if world > 1:
+            rows = multi_gpu.packed_rows(world, H, band)
+            ln.mine = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")
+            ln.gathered = torch.zeros((world * rows, W, 3), dtype=torch.float32, device="cuda")
+        else:
+            ln.mine = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+            ln.gathered = None
+        lanes.append(ln)
     if world > 1:
-        rows = multi_gpu.packed_rows(world, H, band)
-        mine = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")
-        gathered = torch.zeros((world * rows, W, 3), dtype=torch.float32, device="cuda")
         opts = gpu.Options(max_segments=args.max_segments, band_rows=band, band_rank=rank, band_count=world,
                            flags=gpu.FLAG_COMPACT_BANDS)
     else:
-        mine = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
-        gathered = None
         opts = gpu.Options(max_segments=args.max_segments)
+    g = lanes[0].g
     frame = None
+    torch.cuda.synchronize()
 
-    def step(seed, options=opts):
+    def render(ln, seed, options):
+        ln.g.render_region_device(ln.mine.data_ptr(), W, H, (0, 0, W, H), spp, seed, options, ln.stream.cuda_stream)
+
+    def finish_frame(ln):
         nonlocal frame
-        g.render_region_device(mine.data_ptr(), W, H, (0, 0, W, H), spp, seed, options, stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, mine)
-            frame = multi_gpu.assemble(gathered, world, H, W, band)
+            with torch.cuda.stream(ln.stream):
+                dist.all_gather_into_tensor(ln.gathered, ln.mine)
+                frame = multi_gpu.assemble(ln.gathered, world, H, W, band)
         else:
-            frame = mine
+            frame = ln.mine
+
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=in_flight)
+
+    def run_frames(seeds, options=opts, depth=in_flight):
+        """Render one frame per seed, `depth` of them in flight."""
+        pending = {}
+        for j in range(min(depth, len(seeds))):
+            pending[j] = pool.submit(render, lanes[j % depth], seeds[j], options)
+        for i in range(len(seeds)):
+            pending.pop(i).result()
+            finish_frame(lanes[i % depth])
+            if i + depth < len(seeds):
+                pending[i + depth] = pool.submit(render, lanes[(i + depth) % depth], seeds[i + depth], options)
 
     def fence():
         torch.cuda.synchronize()
@@ -155,19 +197,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(10_000 + i)
+    run_frames([20_000 + k for k in range(in_flight)])          # set-up: every lane allocates its device work lists
     fence()
-    g.reset_stats()
+    run_frames([10_000 + i for i in range(args.warmup)])
+    fence()
+    for ln in lanes:
+        ln.g.reset_stats()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run_frames(list(range(args.steps)))
     fence()
     elapsed = time.perf_counter() - t0
-    st = g.stats()
+    rays = float(sum(ln.g.stats()["rays"] for ln in lanes))
 
-    # max over ranks of the time, sum over ranks of the rays
-    rays = float(st["rays"])
+    # kernel durations: frames rendered one at a time (HIP events around every launch; with frames
+    # overlapping, an event pair would also span the other frame's kernels)
+    g.reset_stats()
+    run_frames([0, 1, 2], depth=1)
+    fence()
+    st = g.stats()
     frames = max(1, st["launches"])
     fresh_ms, tree_ms = st["fresh_ms"] / frames, st["tree_ms"] / frames
     resume_ms = (st["shade_ms"] - st["fresh_ms"]) / frames
@@ -183,8 +230,8 @@ def main():
 
     # algorithmic bytes of ONE frame: the same frame (seed 0) with the detailed counters on, untimed
     g.reset_stats()
-    step(0, gpu.Options(max_segments=args.max_segments, flags=opts.flags | gpu.FLAG_DETAILED_STATS,
-                        band_rows=opts.band_rows, band_rank=opts.band_rank, band_count=opts.band_count))
+    run_frames([0], gpu.Options(max_segments=args.max_segments, flags=opts.flags | gpu.FLAG_DETAILED_STATS,
+                                band_rows=opts.band_rows, band_rank=opts.band_rank, band_count=opts.band_count), depth=1)
     torch.cuda.synchronize()
     det = g.stats()
     own_pixels = (H // world) * W
@@ -225,6 +272,7 @@ def main():
                 "rays_per_sample": round(rays / args.steps / (W * H * spp), 3),
                 "ms_per_frame": round(1e3 * elapsed / args.steps, 3),
                 "split": "8-row bands round-robin + all-gather" if world > 1 else "single device",
+                "frames_in_flight": in_flight,
                 "frame_checksum_seed0": checksum,
             },
             "roofline": {
@@ -269,7 +317,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    g.close()
+    pool.shutdown()
+    for ln in lanes:
+        ln.g.close()
 
 
 if __name__ == "__main__":
