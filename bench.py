@@ -216,17 +216,18 @@ def main():
     fence()
     st = g.stats()
     frames = max(1, st["launches"])
-    fresh_ms, tree_ms = st["fresh_ms"] / frames, st["tree_ms"] / frames
+    fresh_ms, tree_ms, finish_ms = st["fresh_ms"] / frames, st["tree_ms"] / frames, st["finish_ms"] / frames
     resume_ms = (st["shade_ms"] - st["fresh_ms"]) / frames
     resume_launches = max(0.0, st["rounds"] / frames - 1)           # each resume launch follows one tree launch
     if world > 1:
-        t = torch.tensor([elapsed, fresh_ms, resume_ms, tree_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, fresh_ms, resume_ms, tree_ms, finish_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         r = torch.tensor([rays], dtype=torch.float64, device="cuda")
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        elapsed, fresh_ms, resume_ms, tree_ms, rays = float(t[0]), float(t[1]), float(t[2]), float(t[3]), float(r[0])
+        elapsed, fresh_ms, resume_ms, tree_ms, finish_ms = (float(x) for x in t)
+        rays = float(r[0])
     shade_ms = fresh_ms + resume_ms
-    kernel_ms = shade_ms + tree_ms
+    kernel_ms = shade_ms + tree_ms + finish_ms
 
     # algorithmic bytes of ONE frame: the same frame (seed 0) with the detailed counters on, untimed
     g.reset_stats()
@@ -283,23 +284,25 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "traffic_source": traffic_source,
-                "kernel": "rt_shade_kernel + rt_tree_kernel, all launches of one frame",
+                "kernel": "rt_shade_kernel + rt_tree_kernel + rt_finish_kernel, all launches of one frame",
                 "kernel_ms": round(kernel_ms, 3),
                 "kernels": {
-                    "rt_shade_kernel": {
-                        "ms_per_frame": round(shade_ms, 3),
-                        "launches_per_frame": round(1 + resume_launches, 2),
-                        "rt_shade_kernel<true, false> (new paths) avg_launch_ms": round(fresh_ms, 3),
-                        "rt_shade_kernel<false, false> (resumed paths) avg_launch_ms":
-                            round(resume_ms / max(1.0, resume_launches), 4),
-                        "algorithmic_bytes": int(shade_bytes),
-                        "achieved": round(shade_bytes / max(1e-9, shade_ms * 1e-3) / 1e9, 1)},
-                    "rt_tree_kernel": {
+                    "rt_shade_kernel<true, false> (new paths)": {
+                        "ms_per_frame": round(fresh_ms, 3), "launches_per_frame": 1,
+                        "avg_launch_ms": round(fresh_ms, 3)},
+                    "rt_shade_kernel<false, false> (resumed paths)": {
+                        "ms_per_frame": round(resume_ms, 3), "launches_per_frame": round(resume_launches, 2),
+                        "avg_launch_ms": round(resume_ms / max(1.0, resume_launches), 4)},
+                    "rt_tree_kernel<false>": {
                         "ms_per_frame": round(tree_ms, 3), "launches_per_frame": round(resume_launches, 2),
-                        "rt_tree_kernel<false> avg_launch_ms": round(tree_ms / max(1.0, resume_launches), 4),
-                        "algorithmic_bytes": int(tree_bytes),
-                        "achieved": round(tree_bytes / max(1e-9, tree_ms * 1e-3) / 1e9, 1)},
+                        "avg_launch_ms": round(tree_ms / max(1.0, resume_launches), 4)},
+                    "rt_finish_kernel<false> (last paths, shading and trees in one launch)": {
+                        "ms_per_frame": round(finish_ms, 3), "launches_per_frame": 1,
+                        "avg_launch_ms": round(finish_ms, 3)},
                 },
+                "algorithmic_bytes_by_work": {
+                    "scene primitives, root boxes, hit attributes, texels, pixels": int(shade_bytes),
+                    "tree nodes and triangles": int(tree_bytes)},
                 "algorithmic_bytes_per_frame": int(abytes),
                 "algorithmic_bytes_per_ray": round(abytes / max(1, det["rays"]), 1),
                 "counted": {k: int(det[k]) for k in ("rays", "shadow_rays", "root_tests", "interior_pops",

@@ -81,7 +81,8 @@ typedef struct rt_gpu_stats {
     double   kernel_ms;      /* device time of the shade + tree kernels (HIP events on their stream) */
     double   shade_ms, tree_ms;  /* ... and each kernel's share */
     double   fresh_ms;           /* part of shade_ms spent in the launches that start new paths (first of each batch) */
-    uint64_t rounds;         /* shade launches (each but the last followed by a tree launch) */
+    double   finish_ms;          /* rt_finish_kernel (last paths of a batch), not part of shade_ms or tree_ms */
+    uint64_t rounds;         /* shade launches (each followed by a tree launch, the last by nothing or by the finish launch) */
     uint64_t overflowed;     /* paths that found the parked list full (always 0: such a call fails) */
     uint32_t launches;       /* render calls x sample batches */
     uint32_t reserved;

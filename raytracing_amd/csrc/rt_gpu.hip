@@ -796,9 +796,9 @@ struct rt_gpu_scene {
     QueueCounters *d_queue = nullptr;
     uint32_t shade_blocks = 0, tree_blocks = 0, finish_blocks = 0;   /* persistent grid sizes */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tree_timers;
-    double tree_ms = 0.0, fresh_ms = 0.0;
+    double tree_ms = 0.0, fresh_ms = 0.0, finish_ms = 0.0;
     uint64_t overflowed = 0, rounds = 0;
-    struct Timer { hipEvent_t first, second; bool fresh; };
+    struct Timer { hipEvent_t first, second; int kind; };      /* 0 resumed paths, 1 new paths, 2 finish */
     std::vector<Timer> timers;                                /* pending kernel timings */
     std::vector<hipEvent_t> spare_events;
     double kernel_ms = 0.0;
@@ -985,8 +985,9 @@ static void settle_timers(rt_gpu_scene *s)
     for (auto &t : s->timers) {
         float ms = 0.0f;
         if (hipEventSynchronize(t.second) == hipSuccess && hipEventElapsedTime(&ms, t.first, t.second) == hipSuccess) {
-            s->kernel_ms += ms;
-            if (t.fresh) s->fresh_ms += ms;
+            if (t.kind == 2) s->finish_ms += ms;
+            else s->kernel_ms += ms;
+            if (t.kind == 1) s->fresh_ms += ms;
         }
         s->spare_events.push_back(t.first);
         s->spare_events.push_back(t.second);
@@ -1136,7 +1137,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
                 else hipLaunchKernelGGL((rt_shade_kernel<false, false>), dim3(grid), dim3(RT_BLOCK), 0, stream, P);
             }
             RT_HIP(hipGetLastError());
-            if (e0 && e1) { RT_HIP(hipEventRecord(e1, stream)); s->timers.push_back({e0, e1, round == 0}); }
+            if (e0 && e1) { RT_HIP(hipEventRecord(e1, stream)); s->timers.push_back({e0, e1, round == 0 ? 1 : 0}); }
             QueueCounters qc;
             RT_HIP(hipMemcpyAsync(&qc, s->d_queue, sizeof(qc), hipMemcpyDeviceToHost, stream));
             RT_HIP(hipStreamSynchronize(stream));
@@ -1168,8 +1169,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
                 if (detailed) hipLaunchKernelGGL(rt_finish_kernel<true>, dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
                 else hipLaunchKernelGGL(rt_finish_kernel<false>, dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
                 RT_HIP(hipGetLastError());
-                if (f0 && f1) { RT_HIP(hipEventRecord(f1, stream)); s->timers.push_back({f0, f1, false}); }
-                s->rounds++;
+                if (f0 && f1) { RT_HIP(hipEventRecord(f1, stream)); s->timers.push_back({f0, f1, 2}); }
                 break;
             }
             /* answer the parked queries, then resume those paths */
@@ -1303,7 +1303,7 @@ int rt_gpu_render_jobs(rt_gpu_scene *s, const rt_job *jobs, uint32_t job_count, 
     else
         hipLaunchKernelGGL(rt_render_jobs_kernel<false>, dim3(grid), dim3(RT_BLOCK), lds, nullptr, P);
     e = hipGetLastError();
-    if (e0 && e1) { (void)hipEventRecord(e1, nullptr); s->timers.push_back({e0, e1, false}); }
+    if (e0 && e1) { (void)hipEventRecord(e1, nullptr); s->timers.push_back({e0, e1, 0}); }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(d_jobs);
     if (e != hipSuccess) return fail(RT_GPU_ERR_DEVICE, std::string("job kernel: ") + hipGetErrorString(e));
@@ -1410,8 +1410,8 @@ int rt_gpu_get_stats(rt_gpu_scene *s, rt_gpu_stats *out)
     out->rng_draws = w[9]; out->light_tests = w[10]; out->sphere_tests = w[11]; out->plane_tests = w[12];
     out->shade_steps = w[13]; out->pop_steps = w[14]; out->tri_steps = w[15];
     out->shade_lanes = w[16]; out->pop_lanes = w[17]; out->tri_lanes = w[18]; out->tree_entries = w[19];
-    out->kernel_ms = s->kernel_ms + s->tree_ms;
-    out->shade_ms = s->kernel_ms; out->tree_ms = s->tree_ms; out->fresh_ms = s->fresh_ms;
+    out->kernel_ms = s->kernel_ms + s->tree_ms + s->finish_ms;
+    out->shade_ms = s->kernel_ms; out->tree_ms = s->tree_ms; out->fresh_ms = s->fresh_ms; out->finish_ms = s->finish_ms;
     out->rounds = s->rounds; out->overflowed = s->overflowed;
     out->launches = s->launches;
     return RT_GPU_OK;
@@ -1424,7 +1424,7 @@ int rt_gpu_reset_stats(rt_gpu_scene *s)
     RT_HIP(hipDeviceSynchronize());
     settle_timers(s);
     RT_HIP(hipMemset(s->d_stats, 0, sizeof(uint64_t) * RT_STAT_WORDS));
-    s->kernel_ms = 0.0; s->tree_ms = 0.0; s->fresh_ms = 0.0; s->launches = 0; s->samples = 0; s->rounds = 0; s->overflowed = 0;
+    s->kernel_ms = 0.0; s->tree_ms = 0.0; s->fresh_ms = 0.0; s->finish_ms = 0.0; s->launches = 0; s->samples = 0; s->rounds = 0; s->overflowed = 0;
     return RT_GPU_OK;
 }
 

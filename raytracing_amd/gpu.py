@@ -43,7 +43,7 @@ class Stats(C.Structure):
         "samples", "rays", "shadow_rays", "root_tests", "interior_pops", "leaf_pops",
         "tri_tests", "tri_hits", "tex_lookups", "rng_draws", "light_tests", "sphere_tests", "plane_tests",
         "shade_steps", "pop_steps", "tri_steps", "shade_lanes", "pop_lanes", "tri_lanes", "tree_entries")] + [
-        ("kernel_ms", C.c_double), ("shade_ms", C.c_double), ("tree_ms", C.c_double), ("fresh_ms", C.c_double),
+        ("kernel_ms", C.c_double), ("shade_ms", C.c_double), ("tree_ms", C.c_double), ("fresh_ms", C.c_double), ("finish_ms", C.c_double),
         ("rounds", C.c_uint64), ("overflowed", C.c_uint64), ("launches", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
