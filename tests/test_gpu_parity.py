@@ -259,6 +259,34 @@ def test_sample_batches_continue_bit_exactly(gpu_scenes):
     assert L.same_bits(got, oracle_counter(sh, W, H, (0, 0, W, H), 3, seed, sample_offset=2)).all()
 
 
+def test_memory_budgets_and_round_policies_do_not_change_the_picture(gpu_scenes, monkeypatch):
+    """How a frame is cut into launches is an implementation matter: a small sample scratch (several
+    sample batches per call), a parked-list budget that forces batches, rounds to the very end
+    (no finishing launch) and a finishing launch right after the first one must all give the
+    oracle's bits; a parked-list budget too small for one sample per pixel is an error."""
+    sh, gs = gpu_scenes("three_dogs")
+    W = H = 96
+    want = oracle_counter(sh, W, H, (0, 0, W, H), 12, 5)
+    cases = [{}, {"RT_GPU_SCRATCH_MB": "1"}, {"RT_GPU_PARKED_MB": "421"}, {"RT_GPU_FINISH_BELOW": "0"},
+             {"RT_GPU_FINISH_BELOW": "4000000000"}, {"RT_GPU_SCRATCH_MB": "1", "RT_GPU_FINISH_BELOW": "0"}]
+    for env in cases:
+        for k in ("RT_GPU_SCRATCH_MB", "RT_GPU_PARKED_MB", "RT_GPU_FINISH_BELOW"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        img, got = host.new_image(W, H)
+        gs.reset_stats()
+        gs.render_region(img, (0, 0, W, H), 12, 5)
+        assert L.same_bits(got, want).all(), env
+        st = gs.stats()
+        if env.get("RT_GPU_SCRATCH_MB") == "1":
+            assert st["launches"] > 1, (env, st["launches"])        # the call really was cut into batches
+    monkeypatch.setenv("RT_GPU_PARKED_MB", "1")
+    img, got = host.new_image(W, H)
+    with pytest.raises(RuntimeError, match="RT_GPU_PARKED_MB"):
+        gs.render_region(img, (0, 0, W, H), 2, 5)
+
+
 def test_path_length_cap(gpu_scenes):
     """max_segments = 5 (the '5 bounces' configuration) and 1."""
     sh, gs = gpu_scenes("diffuse_room")
