@@ -1086,7 +1086,11 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
      * path of the launch at once plus one partly used chunk per wave, so parking never fails. */
     const uint64_t units = (uint64_t)G.blocks_x * G.block_rows;
     const uint64_t items_per_sample = units * 64;
-    const uint64_t chunk_slack = (uint64_t)s->shade_blocks * (RT_BLOCK / 64) * RT_CHUNK;
+    /* no more workgroups than there are portions of fresh work for their waves (small regions) */
+    const uint64_t portions_max = units * ((spp + RT_PORTION_SPP - 1) / RT_PORTION_SPP);
+    uint32_t shade_grid = s->shade_blocks;
+    if ((portions_max + 3) / 4 < shade_grid) shade_grid = (uint32_t)((portions_max + 3) / 4);
+    const uint64_t chunk_slack = (uint64_t)shade_grid * (RT_BLOCK / 64) * RT_CHUNK;
     uint64_t scratch_mb = 4096, parked_mb = 32768;
     if (const char *e = getenv("RT_GPU_SCRATCH_MB")) scratch_mb = (uint64_t)atoll(e);
     if (const char *e = getenv("RT_GPU_PARKED_MB")) parked_mb = (uint64_t)atoll(e);
@@ -1107,7 +1111,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     P.out_capacity = (uint32_t)capacity;
 
     const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
-    const uint32_t shade_grid = s->shade_blocks, tree_grid = s->tree_blocks;
+    const uint32_t tree_grid = s->tree_blocks;
     const uint32_t resolve_grid = (uint32_t)((units * 64 + RT_BLOCK - 1) / RT_BLOCK);
 
     const bool trace_rounds = getenv("RT_GPU_TRACE_ROUNDS") != nullptr;
