@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--scene", default="dog_room")
     ap.add_argument("--max-segments", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-ranks", type=int, default=0,
+                    help="single process, single GPU: act as rank 0 of this many ranks and render the other ranks' "
+                         "shares in place of the all-gather (a check of the multi-GPU path, not a measurement)")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="frames rendered concurrently (each with its own stream and device work lists)")
     args = ap.parse_args()
@@ -131,6 +134,41 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.rehearse_ranks > 1:
+        # One process plays rank 0 of N: the other ranks' shares are rendered here as well, inside
+        # the stand-in for the all-gather.  Exercises the band split, the packed buffers and the
+        # frame pipeline on a single GPU; the numbers it prints are not a benchmark.
+        world = args.rehearse_ranks
+
+        class RehearsalDist:
+            class ReduceOp:
+                MAX, SUM = "max", "sum"
+
+            def __init__(self):
+                self.scene, self.seed = None, 0
+
+            def all_gather_into_tensor(self, out, mine):
+                rows = mine.shape[0]
+                out[:rows].copy_(mine)
+                part = torch.empty_like(mine)
+                for r in range(1, world):
+                    o = gpu.Options(max_segments=args.max_segments, band_rows=multi_gpu.BAND_ROWS, band_rank=r,
+                                    band_count=world, flags=gpu.FLAG_COMPACT_BANDS)
+                    torch.cuda.synchronize()
+                    self.scene.render_region_device(part.data_ptr(), args.width, args.height,
+                                                    (0, 0, args.width, args.height), args.spp, self.seed, o)
+                    torch.cuda.synchronize()
+                    out[r * rows:(r + 1) * rows].copy_(part)
+
+            def all_reduce(self, t, op=None):
+                pass
+
+            def barrier(self):
+                pass
+
+            def destroy_process_group(self):
+                pass
+        dist = RehearsalDist()
 
     W, H, spp = args.width, args.height, args.spp
     band = multi_gpu.BAND_ROWS
@@ -165,13 +203,19 @@ def main():
     frame = None
     torch.cuda.synchronize()
 
+    if args.rehearse_ranks > 1:
+        dist.scene = gpu.GpuScene(sh)
+
     def render(ln, seed, options):
+        ln.seed = seed
         ln.g.render_region_device(ln.mine.data_ptr(), W, H, (0, 0, W, H), spp, seed, options, ln.stream.cuda_stream)
 
     def finish_frame(ln):
         nonlocal frame
         if world > 1:
             with torch.cuda.stream(ln.stream):
+                if args.rehearse_ranks > 1:
+                    dist.seed = ln.seed
                 dist.all_gather_into_tensor(ln.gathered, ln.mine)
                 frame = multi_gpu.assemble(ln.gathered, world, H, W, band)
         else:
