@@ -131,6 +131,16 @@ int rt_gpu_render_region_device(rt_gpu_scene *scene, float *device_pixels, uint3
  * final factor 1/(0.5*0.5*2*pi*spp_total) (src/main.c:788). */
 int rt_gpu_normalize_device(float *device_pixels, size_t pixel_count, uint32_t spp_total, void *hip_stream);
 
+/* save_image's conversion (src/main.c:73-82: min(c,1), powf(c, 1/2.2f), x255, truncation) on
+ * device pixels, 3 bytes per pixel into device memory, on the given stream: the frame leaves
+ * the GPU as 3 MB of RGB8 instead of 12.6 MB of floats.  The power is evaluated in double
+ * (rt_gamma_powf, raytracing_amd/csrc/rt_math_portable.h); checked over every float from 0 to
+ * 1.125 against the host libm's powf: the bytes agree for all 1 066 401 793 inputs but one
+ * (0x3c364a2a, where glibc 2.35's powf is one ulp above the correctly rounded value: 33
+ * instead of 32).  Negative inputs, which the render loop cannot produce, are undefined in
+ * the reference (NaN converted to uint8_t) and give 0 here. */
+int rt_gpu_quantize_device(const float *device_pixels, size_t pixel_count, uint8_t *device_rgb, void *hip_stream);
+
 /* Bit-compatible replay of raytrace_region(Job*) for a batch of jobs, each
  * with its own region, sample count and Random_Serie (Job, src/main.h:65-72):
  * one GPU lane walks one job in the reference's order and consumes the job's

@@ -749,6 +749,13 @@ ORC_EXPORT void orc_quantize(const rt_image3f *image, uint8_t *rgb)
     }
 }
 
+/* the same conversion with the power evaluated by rt_gamma_powf instead of libm: what the
+ * device epilogue computes (oracle/check_gamma.c compares the two over every input) */
+ORC_EXPORT void orc_quantize_portable(const float *values, size_t n, uint8_t *bytes)
+{
+    for (size_t i = 0; i < n; i++) bytes[i] = rt_gamma_byte(values[i]);
+}
+
 /* ------------------------------------------------------------------------ */
 /* threaded tile driver for CPU timing: the shape of src/main.c:804-833      */
 /* (atomic tile counter, one generator stream per tile)                      */

@@ -749,6 +749,13 @@ __global__ void rt_normalize_kernel(float *p, size_t n, float factor)
     if (i < n) p[i] = p[i] * factor;
 }
 
+/* display transfer of save_image (src/main.c:73-82) on device pixels: 3 bytes per pixel */
+__global__ void rt_quantize_kernel(const float *p, size_t n, uint8_t *rgb)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rgb[i] = rt_gamma_byte(p[i]);
+}
+
 __global__ void rt_math_kernel(const float *x, const float *y, size_t n, float *s, float *c, float *l,
                                float *q, float *r, float *qc)
 {
@@ -1256,6 +1263,18 @@ int rt_gpu_normalize_device(float *device_pixels, size_t pixel_count, uint32_t s
     if (!n) return RT_GPU_OK;
     hipLaunchKernelGGL(rt_normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(hip_stream), device_pixels, n, rt_pixel_norm(spp_total));
+    RT_HIP(hipGetLastError());
+    return RT_GPU_OK;
+}
+
+int rt_gpu_quantize_device(const float *device_pixels, size_t pixel_count, uint8_t *device_rgb, void *hip_stream)
+{
+    if (!device_pixels || !device_rgb) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_quantize_device: NULL argument");
+    size_t n = pixel_count * 3;
+    if (!n) return RT_GPU_OK;
+    if ((n + 255) / 256 > 0x7FFFFFFFull) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_quantize_device: image too large");
+    hipLaunchKernelGGL(rt_quantize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(hip_stream), device_pixels, n, device_rgb);
     RT_HIP(hipGetLastError());
     return RT_GPU_OK;
 }

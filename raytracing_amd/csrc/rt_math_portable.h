@@ -109,4 +109,76 @@ RT_MATH_FN float rt_logf(float x)
     return (float)r;
 }
 
+/* c^(1/2.2f) for the display transfer of src/main.c:73-82, c in [0, 1] (c < 0 or NaN: NaN):
+ * exp(g * log c) in double, log as in rt_logf before its final rounding, exp by Cody-Waite
+ * reduction with a split ln 2 and the Taylor series through y^13 (|y| <= 0.35), 2^k put together
+ * from its exponent bits.  Relative error before the rounding to float below 2^-48. */
+RT_MATH_FN float rt_gamma_powf(float c)
+{
+    if (!(c > 0.0f)) {
+        if (c == 0.0f) return 0.0f;
+        return (c - c) + __builtin_nanf("");
+    }
+    if (c == 1.0f) return 1.0f;
+    const double xd = (double)c;
+    uint64_t bits;
+    __builtin_memcpy(&bits, &xd, 8);
+    int e = (int)(bits >> 52) - 1023;
+    bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m;
+    __builtin_memcpy(&m, &bits, 8);
+    if (m > 1.41421356237309514547) { m = m * 0.5; e = e + 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 23.0;
+    p = __builtin_fma(p, s2, 1.0 / 21.0);
+    p = __builtin_fma(p, s2, 1.0 / 19.0);
+    p = __builtin_fma(p, s2, 1.0 / 17.0);
+    p = __builtin_fma(p, s2, 1.0 / 15.0);
+    p = __builtin_fma(p, s2, 1.0 / 13.0);
+    p = __builtin_fma(p, s2, 1.0 / 11.0);
+    p = __builtin_fma(p, s2, 1.0 / 9.0);
+    p = __builtin_fma(p, s2, 1.0 / 7.0);
+    p = __builtin_fma(p, s2, 1.0 / 5.0);
+    p = __builtin_fma(p, s2, 1.0 / 3.0);
+    const double s3 = s * s2;
+    const double atanh_s = __builtin_fma(s3, p, s);
+    const double two_atanh = atanh_s + atanh_s;
+    double l = __builtin_fma((double)e, 1.90821492927058770002e-10, two_atanh);
+    l = __builtin_fma((double)e, 6.93147180369123816490e-01, l);            /* ln c */
+    const double z = l * (double)(1.0f / 2.2f);                               /* the host's float exponent, widened */
+    const double fk = __builtin_rint(z * 1.44269504088896338700e+00);         /* z / ln 2 */
+    double y = __builtin_fma(-fk, 6.93147180369123816490e-01, z);
+    y = __builtin_fma(-fk, 1.90821492927058770002e-10, y);
+    double q = 1.0 / 6227020800.0;                                            /* 1/13! */
+    q = __builtin_fma(q, y, 1.0 / 479001600.0);
+    q = __builtin_fma(q, y, 1.0 / 39916800.0);
+    q = __builtin_fma(q, y, 1.0 / 3628800.0);
+    q = __builtin_fma(q, y, 1.0 / 362880.0);
+    q = __builtin_fma(q, y, 1.0 / 40320.0);
+    q = __builtin_fma(q, y, 1.0 / 5040.0);
+    q = __builtin_fma(q, y, 1.0 / 720.0);
+    q = __builtin_fma(q, y, 1.0 / 120.0);
+    q = __builtin_fma(q, y, 1.0 / 24.0);
+    q = __builtin_fma(q, y, 1.0 / 6.0);
+    q = __builtin_fma(q, y, 0.5);
+    q = __builtin_fma(q, y, 1.0);
+    q = __builtin_fma(q, y, 1.0);                                             /* exp(y) */
+    const int k = (int)fk;                                                    /* -70 <= k <= 0 for c in [2^-149, 1) */
+    const uint64_t scale_bits = (uint64_t)(1023 + k) << 52;
+    double scale;
+    __builtin_memcpy(&scale, &scale_bits, 8);
+    return (float)(q * scale);
+}
+
+/* one channel of save_image (src/main.c:73-82): min(c, 1) with a NaN giving 1, the transfer
+ * function, times 255, truncation */
+RT_MATH_FN uint8_t rt_gamma_byte(float c)
+{
+    float v = c < 1.0f ? c : 1.0f;
+    v = rt_gamma_powf(v);
+    v = v * 255.0f;
+    return (uint8_t)v;
+}
+
 #endif /* RT_MATH_PORTABLE_H */

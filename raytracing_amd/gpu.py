@@ -21,7 +21,7 @@ FLAG_COMPACT_BANDS = 4
 EXPORTS = [
     "rt_gpu_device_count", "rt_gpu_last_error", "rt_gpu_scene_create", "rt_gpu_scene_destroy",
     "rt_gpu_scene_set_camera", "rt_gpu_render_region", "rt_gpu_render_region_device",
-    "rt_gpu_normalize_device", "rt_gpu_render_jobs", "rt_gpu_find_ray_hit", "rt_gpu_find_ray_hit_serial", "rt_gpu_quantize",
+    "rt_gpu_normalize_device", "rt_gpu_render_jobs", "rt_gpu_find_ray_hit", "rt_gpu_find_ray_hit_serial", "rt_gpu_quantize", "rt_gpu_quantize_device",
     "rt_gpu_get_stats", "rt_gpu_reset_stats", "rt_gpu_eval_math",
 ]
 
@@ -87,6 +87,7 @@ def lib():
                                           C.POINTER(T.RayResult)]
         L.rt_gpu_find_ray_hit_serial.argtypes = L.rt_gpu_find_ray_hit.argtypes
         L.rt_gpu_quantize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rt_gpu_quantize_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rt_gpu_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.rt_gpu_reset_stats.argtypes = [C.c_void_p]
         L.rt_gpu_eval_math.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
@@ -168,6 +169,11 @@ def quantize(pixels):
     out = np.zeros(pixels.shape, dtype=np.uint8)
     _check(lib().rt_gpu_quantize(pixels.ctypes.data, pixels.size // 3, out.ctypes.data))
     return out
+
+
+def quantize_device(device_pixels_ptr, pixel_count, device_rgb_ptr, stream=0):
+    """Device float RGB -> device RGB8 (the display transfer of the reference's save_image)."""
+    _check(lib().rt_gpu_quantize_device(device_pixels_ptr, pixel_count, device_rgb_ptr, C.c_void_p(stream)))
 
 
 def eval_math(x, y=None):

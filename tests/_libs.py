@@ -68,6 +68,8 @@ def oracle(contract=False):
         L.orc_logf.restype = None
         L.orc_quantize.argtypes = [C.POINTER(T.Image3f), C.c_void_p]
         L.orc_quantize.restype = None
+        L.orc_quantize_portable.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_quantize_portable.restype = None
         L.orc_render_tiles.argtypes = [
             C.POINTER(T.Scene), C.POINTER(T.Image3f), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
             C.c_int, C.c_int, C.POINTER(T.RandomSerie), C.c_uint64, C.POINTER(Stats)]

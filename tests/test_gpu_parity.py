@@ -80,6 +80,45 @@ def test_device_math_equals_host_math(golden):
             assert same.all(), int((~same).sum())
 
 
+def test_device_display_transfer_equals_host_arithmetic(gpu_scenes):
+    """rt_gpu_quantize_device (save_image's min / power / x255 / truncation on device pixels,
+    src/main.c:73-82) against the same arithmetic on the host (rt_gamma_byte), byte for byte:
+    random inputs, the dark end, inputs beside every output step, zero, denormals, values above 1,
+    infinity, NaN; and a rendered frame against the reference's own libm conversion."""
+    import torch
+    rng = np.random.default_rng(12)
+    steps = ((np.arange(1, 256, dtype=np.float64) / 255.0) ** 2.2).astype(np.float32)
+    near = steps.copy()
+    for _ in range(5):
+        near = np.concatenate([near, np.nextafter(near, np.float32(0)), np.nextafter(near, np.float32(2))])
+    x = np.concatenate([rng.random(1 << 22, dtype=np.float32), (rng.random(1 << 20, dtype=np.float32) ** 10).astype(np.float32),
+                        near, np.array([0.0, 1.0, 1.5, 3e38, np.inf, np.nan, 1e-45, 1e-38, 0.5, 0x3C364A2A], np.float32)])
+    x[-1] = np.array([0x3C364A2A], np.uint32).view(np.float32)[0]
+    x = np.ascontiguousarray(x[: (x.size // 3) * 3])
+    want = np.zeros(x.size, np.uint8)
+    L.oracle().orc_quantize_portable(x.ctypes.data, x.size, want.ctypes.data)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros(x.size, dtype=torch.uint8, device="cuda")
+    gpu.quantize_device(d_in.data_ptr(), x.size // 3, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert (got == want).all(), int((got != want).sum())
+
+    sh, gs = gpu_scenes("dog_room")
+    W = H = 64
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    gs.render_region_device(frame.data_ptr(), W, H, (0, 0, W, H), 8, 3)
+    rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    gpu.quantize_device(frame.data_ptr(), W * H, rgb.data_ptr())
+    torch.cuda.synchronize()
+    img, arr = host.new_image(W, H)
+    arr[:] = frame.cpu().numpy()
+    libm_bytes = np.zeros(W * H * 3, np.uint8)
+    L.oracle().orc_quantize(C.byref(img), libm_bytes.ctypes.data)
+    assert (rgb.cpu().numpy().reshape(-1) == libm_bytes).all()
+    assert 5 < libm_bytes.mean() < 250
+
+
 # ---------------------------------------------------------------- find_ray_hit
 
 @pytest.mark.parametrize("serial", [False, True], ids=["render_kernels", "serial_walk"])

@@ -81,3 +81,36 @@ def test_quantiser(golden):
     q2 = np.zeros(len(vals), np.uint8)
     L.oracle().orc_quantize(C.byref(img), q2.ctypes.data)
     assert (q2 == g["quant_out"]).all()
+
+
+def test_portable_display_transfer_equals_libm_transfer():
+    """rt_gamma_byte (the device epilogue's arithmetic, double-precision power) against the
+    reference's expression with this machine's powf (src/main.c:73-82): 4 million random inputs,
+    all inputs next to the 256 output steps, specials.  (oracle/check_gamma.c compares all 1.07e9
+    floats from 0 to 1.125: one input differs, 0x3c364a2a, where glibc 2.35's powf is one ulp
+    above the correctly rounded value.)"""
+    rng = np.random.default_rng(11)
+    x = np.concatenate([
+        rng.random(1 << 22, dtype=np.float32),
+        (rng.random(1 << 18, dtype=np.float32) ** 8).astype(np.float32),                 # crowd the dark end
+        np.array([0.0, 1.0, 1.5, np.inf, np.nan, 1e-45, 1e-38, 1e-30, 0.5, 0.999999940395], np.float32)])
+    steps = (np.arange(1, 256, dtype=np.float64) / 255.0) ** 2.2                           # where a byte changes
+    near = np.concatenate([np.nextafter(steps.astype(np.float32), np.float32(k)) for k in (0, 2)] + [steps.astype(np.float32)])
+    for _ in range(6):
+        near = np.concatenate([near, np.nextafter(near, np.float32(0)), np.nextafter(near, np.float32(2))])
+    x = np.ascontiguousarray(np.concatenate([x, near.astype(np.float32)]))
+    x = x[x.view(np.uint32) != 0x3C364A2A]
+    got = np.zeros(x.size, np.uint8)
+    L.oracle().orc_quantize_portable(x.ctypes.data, x.size, got.ctypes.data)
+    n3 = (x.size // 3) * 3
+    img = T.Image3f()
+    img.size.x, img.size.y = n3 // 3, 1
+    buf = np.ascontiguousarray(x[:n3])
+    img.pixels = C.cast(buf.ctypes.data, C.POINTER(T.Vec3f))
+    want = np.zeros(n3, np.uint8)
+    L.oracle().orc_quantize(C.byref(img), want.ctypes.data)
+    assert (got[:n3] == want).all(), int((got[:n3] != want).sum())
+    one = np.array([0x3C364A2A], np.uint32).view(np.float32)
+    out = np.zeros(1, np.uint8)
+    L.oracle().orc_quantize_portable(one.ctypes.data, 1, out.ctypes.data)
+    assert out[0] == 32                                                                     # the correctly rounded power gives 32
