@@ -19,13 +19,11 @@
 #include "rt_flatten.h"
 #include "rt_trace.hpp"
 
-#define RT_BLOCK 256                 /* 4 waves; a wave owns an 8x8 pixel block */
+#define RT_BLOCK 256                 /* 4 waves per workgroup */
 #define RT_STAT_WORDS 20
-#ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 2          /* register budget of the render kernel: 512 / this many VGPRs */
-#endif
 #ifndef RT_SHADE_WEIGHT
-#define RT_SHADE_WEIGHT 16            /* scheduler: weight of a lane that wants a shade step, in 1/16ths */
+#define RT_SHADE_WEIGHT 16            /* in-wave scheduler (job replay, finish kernel): weight of a lane that wants a
+                                       * shade step, in 1/16ths of a lane that wants a tree step */
 #endif
 
 /* ------------------------------------------------------------------------ */
