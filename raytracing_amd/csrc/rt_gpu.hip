@@ -523,26 +523,40 @@ rt_finish_kernel(const FinishParams P)
     rt::PathMachine<rt::CounterRng, STATS> pm(P.S, stk, cn);
     pm.half_w = P.half_w; pm.half_h = P.half_h; pm.max_segments = P.max_segments;
     pm.rng.seed0 = P.seed0; pm.rng.seed1 = P.seed1;
-    for (;;) {
-        uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(&P.q->in_next, 64u);
-        const uint32_t base = __builtin_amdgcn_readfirstlane(v);
-        if (base >= P.slots) break;
-        const uint32_t idx = base + lane;
-        uint32_t sample_index = 0;
-        pm.phase = rt::PH_DEAD;
-        if (idx < P.slots && pm.load_record(P.list + (size_t)idx * RT_RECORD_WORDS, sample_index)) {
-            pm.tv.inst = (int)(P.list[(size_t)idx * RT_RECORD_WORDS + 15] & 0xFFFFu);   /* instance the ray was parked for */
-            pm.phase = rt::PH_SCAN;
-            if (STATS) cn.root_tests--;                  /* counted when the ray was parked */
-        }
-        pm.run(RT_SHADE_WEIGHT, [&]() {
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    uint32_t sample_index = 0;
+    uint32_t in_cur = 0, in_end = 0;
+    bool input_done = false;
+    pm.phase = rt::PH_DEAD;
+    pm.run(RT_SHADE_WEIGHT,
+        [&]() {                                          /* a path ended */
             const rt::f3 c = pm.path_value();
             float *dst = P.samples + 3 * (size_t)sample_index;
             dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
             pm.phase = rt::PH_DEAD;
+        },
+        [&]() {                                          /* free lanes take the next records, a quarter wave at a time */
+            while (!input_done) {
+                const unsigned long long need = __ballot(pm.phase == rt::PH_DEAD);
+                if (__popcll(need) < 16) break;
+                if (in_cur >= in_end) {
+                    uint32_t v = 0;
+                    if (lane == 0) v = atomicAdd(&P.q->in_next, 64u);
+                    in_cur = __builtin_amdgcn_readfirstlane(v);
+                    if (in_cur >= P.slots) { input_done = true; break; }
+                    in_end = in_cur + 64u < P.slots ? in_cur + 64u : P.slots;
+                }
+                const uint32_t idx = in_cur + (uint32_t)__popcll(need & lanes_below);
+                if (pm.phase == rt::PH_DEAD && idx < in_end &&
+                    pm.load_record(P.list + (size_t)idx * RT_RECORD_WORDS, sample_index)) {
+                    pm.tv.inst = (int)(P.list[(size_t)idx * RT_RECORD_WORDS + 15] & 0xFFFFu);   /* instance the ray was parked for */
+                    pm.phase = rt::PH_SCAN;
+                    if (STATS) cn.root_tests--;          /* counted when the ray was parked */
+                }
+                in_cur += (uint32_t)__popcll(need);
+                if (in_cur > in_end) in_cur = in_end;
+            }
         });
-    }
     flush_counters<STATS>(cn, P.stats);
 }
 

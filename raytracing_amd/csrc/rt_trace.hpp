@@ -1021,7 +1021,16 @@ struct PathMachine {
     template <class OnEnd>
     __device__ __forceinline__ void run(int shade_weight_q4, OnEnd &&on_end)
     {
+        run(shade_weight_q4, on_end, []() {});
+    }
+
+    /* refill() is called at the top of every iteration, by all lanes: it may give PH_DEAD lanes
+     * a new path (the loop ends when every lane is dead after it) */
+    template <class OnEnd, class Refill>
+    __device__ __forceinline__ void run(int shade_weight_q4, OnEnd &&on_end, Refill &&refill)
+    {
         for (;;) {
+            refill();
             const int n_shade = __popcll(__ballot(wants_shade()));
             const int n_tri = __popcll(__ballot(wants_tri()));
             const int n_pop = __popcll(__ballot(wants_pop()));
