@@ -88,6 +88,9 @@ __device__ __forceinline__ void flush_counters(const rt::Counters &cn, uint64_t 
 #ifndef RT_TREE_BOTH
 #define RT_TREE_BOTH 12               /* tree kernel: lanes that make the minority kind of step worth running too */
 #endif
+#ifndef RT_SMALL_CHUNK
+#define RT_SMALL_CHUNK 64u              /* the same in rounds with few paths (less padding for the next launch to skip) */
+#endif
 #define RT_CHUNK 256u                /* parked-list slots a wave reserves per atomic */
 
 struct QueueCounters {               /* device words, zeroed per launch where noted */
@@ -116,6 +119,12 @@ struct ShadeParams {
     float    half_w, half_h;
 };
 
+#ifndef RT_IN_BATCH
+#define RT_IN_BATCH 256u              /* list slots a resumed-path wave takes per atomic on the shared cursor */
+#endif
+#ifndef RT_TREE_IN_BATCH
+#define RT_TREE_IN_BATCH 128u         /* the same for a tree-kernel wave */
+#endif
 #ifndef RT_PORTION_SPP
 #define RT_PORTION_SPP 8u             /* samples per pixel in one portion of fresh work (x 64 pixels) */
 #endif
@@ -125,8 +134,11 @@ struct ShadeParams {
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4              /* waves per SIMD the shade kernel is compiled for (0: compiler's choice) */
 #endif
+#ifndef RT_RESUME_WAVES
+#define RT_RESUME_WAVES RT_SHADE_WAVES
+#endif
 #if RT_SHADE_WAVES
-#define RT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES)))
+#define RT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(FRESH ? RT_SHADE_WAVES : RT_RESUME_WAVES, FRESH ? RT_SHADE_WAVES : RT_RESUME_WAVES)))
 #else
 #define RT_SHADE_ATTR
 #endif
@@ -198,10 +210,10 @@ rt_shade_kernel(const ShadeParams P)
             } else {
                 if (in_cur >= in_end) {                  /* next 64 slots of the parked list */
                     uint32_t v = 0;
-                    if (lane == 0) v = atomicAdd(&P.q->in_next, 64u);
+                    if (lane == 0) v = atomicAdd(&P.q->in_next, RT_IN_BATCH);
                     in_cur = __builtin_amdgcn_readfirstlane(v);
                     if (in_cur >= P.in_slots) { input_done = true; break; }
-                    in_end = in_cur + 64u < P.in_slots ? in_cur + 64u : P.in_slots;
+                    in_end = in_cur + RT_IN_BATCH < P.in_slots ? in_cur + RT_IN_BATCH : P.in_slots;
                 }
                 const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
                 const uint32_t idx = in_cur + rank;
@@ -345,10 +357,10 @@ rt_tree_kernel(const TreeParams P)
             if (!need) break;
             if (in_cur >= in_end) {
                 uint32_t v = 0;
-                if (lane == 0) v = atomicAdd(&P.q->in_next, 64u);
+                if (lane == 0) v = atomicAdd(&P.q->in_next, RT_TREE_IN_BATCH);
                 in_cur = __builtin_amdgcn_readfirstlane(v);
                 if (in_cur >= P.slots) { input_done = true; break; }
-                in_end = in_cur + 64u < P.slots ? in_cur + 64u : P.slots;
+                in_end = in_cur + RT_TREE_IN_BATCH < P.slots ? in_cur + RT_TREE_IN_BATCH : P.slots;
             }
             const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
             const uint32_t idx = in_cur + rank;
@@ -813,7 +825,7 @@ struct rt_gpu_scene {
     float *d_samples = nullptr; uint64_t scratch_bytes = 0;   /* per-sample values between shading and resolve */
     uint32_t *d_parked[2] = {nullptr, nullptr}; uint64_t parked_records = 0;   /* paths in transit, ping-pong */
     QueueCounters *d_queue = nullptr;
-    uint32_t shade_blocks = 0, tree_blocks = 0, finish_blocks = 0;   /* persistent grid sizes */
+    uint32_t shade_blocks = 0, resume_blocks = 0, tree_blocks = 0, finish_blocks = 0;   /* persistent grid sizes */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tree_timers;
     double tree_ms = 0.0, fresh_ms = 0.0, finish_ms = 0.0;
     uint64_t overflowed = 0, rounds = 0;
@@ -946,6 +958,9 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
             int per_cu_finish = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_finish, rt_finish_kernel<false>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_finish < 1) per_cu_finish = 1;
             s->finish_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_finish);
+            int per_cu_resume = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_resume, rt_shade_kernel<false, false>, RT_BLOCK, 0) != hipSuccess || per_cu_resume < 1) per_cu_resume = 1;
+            s->resume_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_resume);
             s->shade_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_shade);
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
         }
@@ -1137,6 +1152,8 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     uint32_t finish_below = 262144;                     /* parked records at or below which one launch finishes the paths */
     if (const char *e = getenv("RT_GPU_FINISH_BELOW")) finish_below = (uint32_t)atoll(e);
     auto trace_t = std::chrono::steady_clock::now();
+    uint64_t trace_w[RT_STAT_WORDS] = {0};
+    if (trace_rounds && detailed) (void)hipMemcpy(trace_w, s->d_stats, sizeof(trace_w), hipMemcpyDeviceToHost);
     for (uint32_t first = 0; first < spp; first += (uint32_t)per_launch) {
         P.first_sample = first;
         P.launch_spp = (uint32_t)(spp - first < per_launch ? spp - first : per_launch);
@@ -1147,9 +1164,12 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
             P.in_list = list_in; P.in_slots = in_slots; P.out_list = list_out;
             /* few records per wave: reserve output slots in smaller chunks (less padding to skip later)
              * and launch no more workgroups than there are 64-record portions of input */
-            P.chunk = (round == 0 || in_records >= (4u << 20)) ? RT_CHUNK : 64u;
+            P.chunk = (round == 0 || in_records >= (4u << 20)) ? RT_CHUNK : RT_SMALL_CHUNK;
             uint32_t grid = shade_grid;
-            if (round > 0 && (in_slots + 255) / 256 < grid) grid = (in_slots + 255) / 256;
+            if (round > 0) {
+                if (s->resume_blocks < grid) grid = s->resume_blocks;
+                if ((in_slots + 255) / 256 < grid) grid = (in_slots + 255) / 256;
+            }
             hipEvent_t e0 = take_event(s), e1 = take_event(s);
             if (e0 && e1) RT_HIP(hipEventRecord(e0, stream));
             if (round == 0) {
@@ -1175,6 +1195,16 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
                 if (round > 0 && !s->tree_timers.empty()) (void)hipEventElapsedTime(&tree_ms, s->tree_timers.back().first, s->tree_timers.back().second);
                 fprintf(stderr, "round %u: in %u records (%u slots) -> parked %u records (%u slots); tree %.3f ms, shade %.3f ms, host %.3f ms since the previous read-back\n",
                         round, in_records, in_slots, qc.parked, parked, tree_ms, shade_ms, std::chrono::duration<double, std::milli>(now - trace_t).count());
+                if (detailed) {                          /* step counters of this round's launches */
+                    uint64_t w[RT_STAT_WORDS];
+                    if (hipMemcpy(w, s->d_stats, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess) {
+                        fprintf(stderr, "         shade steps %llu (%.1f lanes), node steps %llu (%.1f lanes), leaf steps %llu (%.1f lanes)\n",
+                                (unsigned long long)(w[13] - trace_w[13]), (double)(w[16] - trace_w[16]) / (double)(w[13] - trace_w[13] + 1),
+                                (unsigned long long)(w[14] - trace_w[14]), (double)(w[17] - trace_w[17]) / (double)(w[14] - trace_w[14] + 1),
+                                (unsigned long long)(w[15] - trace_w[15]), (double)(w[18] - trace_w[18]) / (double)(w[15] - trace_w[15] + 1));
+                        memcpy(trace_w, w, sizeof(w));
+                    }
+                }
                 trace_t = now;
             }
             if (parked == 0) break;
