@@ -119,6 +119,8 @@ struct ShadeParams {
     float    half_w, half_h;
 };
 
+#define RT_STAGE 32u                  /* records per LDS buffer of a resumed-path wave (x 160 bytes, two buffers per wave) */
+#define RT_STAGE_LDS ((size_t)(RT_BLOCK / 64) * 2u * RT_STAGE * 160u)
 #ifndef RT_IN_BATCH
 #define RT_IN_BATCH 256u              /* list slots a resumed-path wave takes per atomic on the shared cursor */
 #endif
@@ -166,8 +168,38 @@ rt_shade_kernel(const ShadeParams P)
     const uint32_t parts = (P.launch_spp + RT_PORTION_SPP - 1u) / RT_PORTION_SPP;
     uint32_t unit = 0, item_next = 0, unit_items = 0;   /* fresh: current block, next item and end of the portion */
     uint32_t bx = 0, by = 0;
-    uint32_t in_cur = 0, in_end = 0;                    /* resume: reserved input range */
+    uint32_t in_cur = 0, in_end = 0;                    /* resume: slots taken from the shared cursor, not yet staged */
+    bool cursor_done = false;
+    uint32_t buf_n[2] = {0u, 0u}, use_b = 0, use_pos = 0;   /* resume: records in each LDS buffer; buffer and position being read */
     bool input_done = false;
+    extern __shared__ uint32_t lds[];
+    uint32_t *stage = lds + (threadIdx.x >> 6) * (2u * RT_STAGE * 40u);      /* per wave: 2 buffers x RT_STAGE records x 10 quads,
+                                                                               * quad q of slot i at word (q * RT_STAGE + i) * 4 */
+    auto stage_into = [&](uint32_t b) {                  /* request the next RT_STAGE slots of the list into buffer b */
+        if (in_cur >= in_end && !cursor_done) {
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(&P.q->in_next, RT_IN_BATCH);
+            in_cur = __builtin_amdgcn_readfirstlane(v);
+            if (in_cur >= P.in_slots) { cursor_done = true; in_end = in_cur; }
+            else in_end = in_cur + RT_IN_BATCH < P.in_slots ? in_cur + RT_IN_BATCH : P.in_slots;
+        }
+        const uint32_t n = in_end - in_cur < RT_STAGE ? in_end - in_cur : RT_STAGE;
+        if (lane < n) {
+            const uint32_t *src = P.in_list + (size_t)(in_cur + lane) * RT_RECORD_WORDS;
+            uint32_t *dst = stage + b * (RT_STAGE * 40u);
+#pragma unroll
+            for (uint32_t qd = 0; qd < 10u; qd++)
+                __builtin_amdgcn_global_load_lds(src + 4u * qd, dst + 4u * RT_STAGE * qd, 16, 0, 0);
+        }
+        buf_n[b] = n;
+        in_cur += n;
+    };
+    if (!FRESH) {                                        /* fill both buffers; reading starts with buffer 1 */
+        stage_into(1u);
+        stage_into(0u);
+        __builtin_amdgcn_s_waitcnt(0x0F70);              /* vmcnt(0) */
+        use_b = 1u; use_pos = 0;
+    }
     uint32_t out_cur = 0, out_end = 0;                  /* reserved output range */
     uint32_t parked_here = 0;
 
@@ -208,19 +240,22 @@ rt_shade_kernel(const ShadeParams P)
                 item_next += (uint32_t)__popcll(need);
                 if (item_next > unit_items) item_next = unit_items;
             } else {
-                if (in_cur >= in_end) {                  /* next 64 slots of the parked list */
-                    uint32_t v = 0;
-                    if (lane == 0) v = atomicAdd(&P.q->in_next, RT_IN_BATCH);
-                    in_cur = __builtin_amdgcn_readfirstlane(v);
-                    if (in_cur >= P.in_slots) { input_done = true; break; }
-                    in_end = in_cur + RT_IN_BATCH < P.in_slots ? in_cur + RT_IN_BATCH : P.in_slots;
+                /* Records reach the lanes through two LDS buffers of RT_STAGE slots each, filled straight
+                 * from the list (global_load_lds: no registers, nothing to wait for at issue).  While
+                 * the lanes take records from one buffer the other is on its way, so the fetch of a
+                 * record is a full buffer ahead of its use. */
+                if (use_pos >= buf_n[use_b]) {
+                    if (buf_n[use_b ^ 1u] == 0u) { input_done = true; break; }   /* nothing staged, nothing left to stage */
+                    __builtin_amdgcn_s_waitcnt(0x0F70);  /* vmcnt(0): the other buffer has landed */
+                    stage_into(use_b);
+                    use_b ^= 1u; use_pos = 0;
                 }
                 const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
-                const uint32_t idx = in_cur + rank;
-                if (!has && idx < in_end)
-                    has = pm.load_record(P.in_list + (size_t)idx * RT_RECORD_WORDS, sample_index);
-                in_cur += (uint32_t)__popcll(need);
-                if (in_cur > in_end) in_cur = in_end;
+                const uint32_t idx = use_pos + rank;
+                if (!has && idx < buf_n[use_b])
+                    has = pm.load_record(reinterpret_cast<const uint4 *>(stage + use_b * (RT_STAGE * 40u)) + idx, RT_STAGE, sample_index);
+                use_pos += (uint32_t)__popcll(need);
+                if (use_pos > buf_n[use_b]) use_pos = buf_n[use_b];
             }
             if (__ballot(has) == ~0ull) break;
         }
@@ -959,7 +994,7 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_finish, rt_finish_kernel<false>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_finish < 1) per_cu_finish = 1;
             s->finish_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_finish);
             int per_cu_resume = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_resume, rt_shade_kernel<false, false>, RT_BLOCK, 0) != hipSuccess || per_cu_resume < 1) per_cu_resume = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_resume, rt_shade_kernel<false, false>, RT_BLOCK, RT_STAGE_LDS) != hipSuccess || per_cu_resume < 1) per_cu_resume = 1;
             s->resume_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_resume);
             s->shade_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_shade);
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
@@ -1176,8 +1211,8 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
                 if (detailed) hipLaunchKernelGGL((rt_shade_kernel<true, true>), dim3(grid), dim3(RT_BLOCK), 0, stream, P);
                 else hipLaunchKernelGGL((rt_shade_kernel<true, false>), dim3(grid), dim3(RT_BLOCK), 0, stream, P);
             } else {
-                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<false, true>), dim3(grid), dim3(RT_BLOCK), 0, stream, P);
-                else hipLaunchKernelGGL((rt_shade_kernel<false, false>), dim3(grid), dim3(RT_BLOCK), 0, stream, P);
+                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<false, true>), dim3(grid), dim3(RT_BLOCK), RT_STAGE_LDS, stream, P);
+                else hipLaunchKernelGGL((rt_shade_kernel<false, false>), dim3(grid), dim3(RT_BLOCK), RT_STAGE_LDS, stream, P);
             }
             RT_HIP(hipGetLastError());
             if (e0 && e1) { RT_HIP(hipEventRecord(e1, stream)); s->timers.push_back({e0, e1, round == 0 ? 1 : 0}); }

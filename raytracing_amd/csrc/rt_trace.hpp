@@ -960,10 +960,17 @@ struct PathMachine {
     /* false = the slot holds no path */
     __device__ __forceinline__ bool load_record(const uint32_t *rec, uint32_t &sample_index)
     {
-        const uint4 *q = reinterpret_cast<const uint4 *>(rec);
+        return load_record(reinterpret_cast<const uint4 *>(rec), 1u, sample_index);
+    }
+
+    /* the record's ten 16-byte quads are `stride` quads apart (1: a record in memory; more: a batch
+     * of records staged quad by quad in LDS) */
+    __device__ __forceinline__ bool load_record(const uint4 *q, uint32_t stride, uint32_t &sample_index)
+    {
         const uint4 a = q[0];
         if (!(a.x & 1u)) return false;
-        const uint4 b = q[1], c = q[2], e = q[3], f = q[4], g = q[5], i = q[6], j = q[7], k = q[8], l = q[9];
+        const uint4 b = q[stride], c = q[2 * stride], e = q[3 * stride], f = q[4 * stride], g = q[5 * stride],
+                    i = q[6 * stride], j = q[7 * stride], k = q[8 * stride], l = q[9 * stride];
         ev = (int)((a.x >> 1) & 3u); ray = (int)((a.x >> 3) & 3u); inside_glass = ((a.x >> 5) & 1u) != 0;
         rng.fresh = ((a.x >> 6) & 1u) != 0; seg = (int)(a.x >> 8);
         x = a.y & 0xFFFFu; y = a.y >> 16;
