@@ -236,10 +236,13 @@ __device__ __forceinline__ void slab_cached(f3 lo, f3 hi, f3 o, f3 d, f3 y, floa
           az = div_by_cached(lo.z - o.z, d.z, y.z);
     float bx = div_by_cached(hi.x - o.x, d.x, y.x), by = div_by_cached(hi.y - o.y, d.y, y.y),
           bz = div_by_cached(hi.z - o.z, d.z, y.z);
-    float nx = sel_min(ax, bx), ny = sel_min(ay, by), nz = sel_min(az, bz);
-    float fx = sel_max(ax, bx), fy = sel_max(ay, by), fz = sel_max(az, bz);
-    enter = sel_max(sel_max(nx, ny), nz);
-    leave = sel_min(sel_min(fx, fy), fz);
+    /* every quotient is finite here (the guard excludes zero divisors and non-finite operands), so the
+     * hardware minimum / maximum give what the host's select macros give, up to the sign of a zero,
+     * which no later comparison can see: one instruction instead of compare + select */
+    float nx = __builtin_fminf(ax, bx), ny = __builtin_fminf(ay, by), nz = __builtin_fminf(az, bz);
+    float fx = __builtin_fmaxf(ax, bx), fy = __builtin_fmaxf(ay, by), fz = __builtin_fmaxf(az, bz);
+    enter = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+    leave = __builtin_fminf(__builtin_fminf(fx, fy), fz);
 }
 
 /* ball test shared by lights and spheres, src/main.c:283-308 */
