@@ -14,7 +14,8 @@
  *
  * Plain C: pointers and sizes only.  All entry points return 0 on success and
  * a negative rt_gpu_status otherwise; rt_gpu_last_error() gives the text.
- * A scene handle may be used by one host thread at a time.
+ * A scene handle may be used by one host thread at a time; different handles
+ * (also of the same scene) may be used concurrently, each on its own stream.
  */
 #ifndef RT_GPU_H
 #define RT_GPU_H
@@ -78,7 +79,7 @@ typedef struct rt_gpu_stats {
     uint64_t shade_lanes, pop_lanes, tri_lanes;  /* ... and the lanes that took part in them (of 64 each) */
     uint64_t tree_entries;                       /* (ray, instance) pairs whose tree was entered          */
                              /* all but the first line only with RT_GPU_FLAG_DETAILED_STATS */
-    double   kernel_ms;      /* device time of the shade + tree kernels (HIP events on their stream) */
+    double   kernel_ms;      /* device time of the shade, tree and finish kernels (HIP events on their stream) */
     double   shade_ms, tree_ms;  /* ... and each kernel's share */
     double   fresh_ms;           /* part of shade_ms spent in the launches that start new paths (first of each batch) */
     double   finish_ms;          /* rt_finish_kernel (last paths of a batch), not part of shade_ms or tree_ms */
@@ -120,9 +121,13 @@ int rt_gpu_render_region(rt_gpu_scene *scene, rt_image3f *image, rt_rect2u regio
                          uint32_t spp, uint64_t seed, const rt_gpu_options *options);
 
 /* The same render into DEVICE memory (width*height float RGB triples, or the
- * packed bands of this rank with RT_GPU_FLAG_COMPACT_BANDS), asynchronous on
- * `hip_stream` (a hipStream_t; NULL = the default stream).  The buffer belongs
- * to the caller (e.g. a tensor that a collective will gather). */
+ * packed bands of this rank with RT_GPU_FLAG_COMPACT_BANDS), on `hip_stream` (a
+ * hipStream_t; NULL = the default stream).  A frame is a sequence of launches
+ * whose number depends on the scene, with a 20-byte read-back after each round:
+ * the call returns once the last round has been read back; the final per-pixel
+ * sum may still be running on the stream, so work that consumes the pixels goes
+ * on the same stream (or synchronises with it).  The buffer belongs to the
+ * caller (e.g. a tensor that a collective will gather). */
 int rt_gpu_render_region_device(rt_gpu_scene *scene, float *device_pixels, uint32_t width, uint32_t height,
                                 rt_rect2u region, uint32_t spp, uint64_t seed,
                                 const rt_gpu_options *options, void *hip_stream);
