@@ -26,6 +26,26 @@
 #define RT_MATH_FN static inline
 #endif
 
+/* RT_K(c): a double constant of a polynomial.  On the host it is the literal.  In gfx950 device
+ * code a 64-bit constant cannot be an instruction operand; the compiler builds each one in a
+ * register pair and, inside a loop, keeps all of them alive from before the loop on: the thirty
+ * constants of the functions below then hold sixty vector registers (or get spilled to scratch
+ * memory).  Here every use makes its constant afresh in a scalar register pair with two scalar
+ * moves, right where a multiply-add reads it: same value, no long-lived registers. */
+#if defined(__HIP_DEVICE_COMPILE__)
+template <unsigned long long BITS>
+__device__ static inline double rt_k_scalar()
+{
+    unsigned lo, hi;
+    __asm__ volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi)
+                     : "i"((unsigned)(BITS & 0xFFFFFFFFull)), "i"((unsigned)(BITS >> 32)));
+    return __hiloint2double((int)hi, (int)lo);
+}
+#define RT_K(c) rt_k_scalar<__builtin_bit_cast(unsigned long long, (double)(c))>()
+#else
+#define RT_K(c) (c)
+#endif
+
 /* sine and cosine of a float argument (radians), |x| <= 2^20; NaN beyond.
  * Cody-Waite reduction to |y| <= pi/4 with a 33-bit + 53-bit split of pi/2
  * (n * hi is exact), then Taylor polynomials through y^15 / y^16. */
@@ -38,29 +58,29 @@ RT_MATH_FN void rt_sincosf(float x, float *sin_out, float *cos_out)
         *cos_out = bad + __builtin_nanf("");
         return;
     }
-    const double fn = __builtin_rint(xd * 6.36619772367581382433e-01);       /* x * 2/pi */
-    double y = __builtin_fma(-fn, 1.57079632673412561417e+00, xd);          /* pi/2, high 33 bits */
-    y = __builtin_fma(-fn, 6.07710050650619224932e-11, y);                   /* pi/2, the rest */
+    const double fn = __builtin_rint(xd * RT_K(6.36619772367581382433e-01));       /* x * 2/pi */
+    double y = __builtin_fma(-fn, RT_K(1.57079632673412561417e+00), xd);          /* pi/2, high 33 bits */
+    y = __builtin_fma(-fn, RT_K(6.07710050650619224932e-11), y);                   /* pi/2, the rest */
     const int q = (int)fn & 3;
     const double y2 = y * y;
 
-    double ps = 1.0 / 1307674368000.0;                                       /* 1/15! */
-    ps = __builtin_fma(ps, y2, -1.0 / 6227020800.0);                         /* 1/13! */
-    ps = __builtin_fma(ps, y2, 1.0 / 39916800.0);
-    ps = __builtin_fma(ps, y2, -1.0 / 362880.0);
-    ps = __builtin_fma(ps, y2, 1.0 / 5040.0);
-    ps = __builtin_fma(ps, y2, -1.0 / 120.0);
-    ps = __builtin_fma(ps, y2, 1.0 / 6.0);
+    double ps = RT_K(1.0 / 1307674368000.0);                                       /* 1/15! */
+    ps = __builtin_fma(ps, y2, RT_K(-1.0 / 6227020800.0));                         /* 1/13! */
+    ps = __builtin_fma(ps, y2, RT_K(1.0 / 39916800.0));
+    ps = __builtin_fma(ps, y2, RT_K(-1.0 / 362880.0));
+    ps = __builtin_fma(ps, y2, RT_K(1.0 / 5040.0));
+    ps = __builtin_fma(ps, y2, RT_K(-1.0 / 120.0));
+    ps = __builtin_fma(ps, y2, RT_K(1.0 / 6.0));
     const double y3 = y * y2;
     const double sv = __builtin_fma(-y3, ps, y);                             /* y - y^3 (1/6 - ...) */
 
-    double pc = 1.0 / 20922789888000.0;                                      /* 1/16! */
-    pc = __builtin_fma(pc, y2, -1.0 / 87178291200.0);                        /* 1/14! */
-    pc = __builtin_fma(pc, y2, 1.0 / 479001600.0);
-    pc = __builtin_fma(pc, y2, -1.0 / 3628800.0);
-    pc = __builtin_fma(pc, y2, 1.0 / 40320.0);
-    pc = __builtin_fma(pc, y2, -1.0 / 720.0);
-    pc = __builtin_fma(pc, y2, 1.0 / 24.0);
+    double pc = RT_K(1.0 / 20922789888000.0);                                      /* 1/16! */
+    pc = __builtin_fma(pc, y2, RT_K(-1.0 / 87178291200.0));                        /* 1/14! */
+    pc = __builtin_fma(pc, y2, RT_K(1.0 / 479001600.0));
+    pc = __builtin_fma(pc, y2, RT_K(-1.0 / 3628800.0));
+    pc = __builtin_fma(pc, y2, RT_K(1.0 / 40320.0));
+    pc = __builtin_fma(pc, y2, RT_K(-1.0 / 720.0));
+    pc = __builtin_fma(pc, y2, RT_K(1.0 / 24.0));
     pc = __builtin_fma(pc, y2, -0.5);
     const double cv = __builtin_fma(y2, pc, 1.0);
 
@@ -89,23 +109,23 @@ RT_MATH_FN float rt_logf(float x)
     if (m > 1.41421356237309514547) { m = m * 0.5; e = e + 1; }
     const double s = (m - 1.0) / (m + 1.0);
     const double s2 = s * s;
-    double p = 1.0 / 23.0;
-    p = __builtin_fma(p, s2, 1.0 / 21.0);
-    p = __builtin_fma(p, s2, 1.0 / 19.0);
-    p = __builtin_fma(p, s2, 1.0 / 17.0);
-    p = __builtin_fma(p, s2, 1.0 / 15.0);
-    p = __builtin_fma(p, s2, 1.0 / 13.0);
-    p = __builtin_fma(p, s2, 1.0 / 11.0);
-    p = __builtin_fma(p, s2, 1.0 / 9.0);
-    p = __builtin_fma(p, s2, 1.0 / 7.0);
-    p = __builtin_fma(p, s2, 1.0 / 5.0);
-    p = __builtin_fma(p, s2, 1.0 / 3.0);
+    double p = RT_K(1.0 / 23.0);
+    p = __builtin_fma(p, s2, RT_K(1.0 / 21.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 19.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 17.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 15.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 13.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 11.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 9.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 7.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 5.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 3.0));
     const double s3 = s * s2;
     const double atanh_s = __builtin_fma(s3, p, s);
     const double two_atanh = atanh_s + atanh_s;
     /* ln 2 split so that e * hi is exact (hi has 32 significant bits) */
-    double r = __builtin_fma((double)e, 1.90821492927058770002e-10, two_atanh);
-    r = __builtin_fma((double)e, 6.93147180369123816490e-01, r);
+    double r = __builtin_fma((double)e, RT_K(1.90821492927058770002e-10), two_atanh);
+    r = __builtin_fma((double)e, RT_K(6.93147180369123816490e-01), r);
     return (float)r;
 }
 
@@ -130,37 +150,37 @@ RT_MATH_FN float rt_gamma_powf(float c)
     if (m > 1.41421356237309514547) { m = m * 0.5; e = e + 1; }
     const double s = (m - 1.0) / (m + 1.0);
     const double s2 = s * s;
-    double p = 1.0 / 23.0;
-    p = __builtin_fma(p, s2, 1.0 / 21.0);
-    p = __builtin_fma(p, s2, 1.0 / 19.0);
-    p = __builtin_fma(p, s2, 1.0 / 17.0);
-    p = __builtin_fma(p, s2, 1.0 / 15.0);
-    p = __builtin_fma(p, s2, 1.0 / 13.0);
-    p = __builtin_fma(p, s2, 1.0 / 11.0);
-    p = __builtin_fma(p, s2, 1.0 / 9.0);
-    p = __builtin_fma(p, s2, 1.0 / 7.0);
-    p = __builtin_fma(p, s2, 1.0 / 5.0);
-    p = __builtin_fma(p, s2, 1.0 / 3.0);
+    double p = RT_K(1.0 / 23.0);
+    p = __builtin_fma(p, s2, RT_K(1.0 / 21.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 19.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 17.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 15.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 13.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 11.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 9.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 7.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 5.0));
+    p = __builtin_fma(p, s2, RT_K(1.0 / 3.0));
     const double s3 = s * s2;
     const double atanh_s = __builtin_fma(s3, p, s);
     const double two_atanh = atanh_s + atanh_s;
-    double l = __builtin_fma((double)e, 1.90821492927058770002e-10, two_atanh);
-    l = __builtin_fma((double)e, 6.93147180369123816490e-01, l);            /* ln c */
+    double l = __builtin_fma((double)e, RT_K(1.90821492927058770002e-10), two_atanh);
+    l = __builtin_fma((double)e, RT_K(6.93147180369123816490e-01), l);            /* ln c */
     const double z = l * (double)(1.0f / 2.2f);                               /* the host's float exponent, widened */
-    const double fk = __builtin_rint(z * 1.44269504088896338700e+00);         /* z / ln 2 */
-    double y = __builtin_fma(-fk, 6.93147180369123816490e-01, z);
-    y = __builtin_fma(-fk, 1.90821492927058770002e-10, y);
-    double q = 1.0 / 6227020800.0;                                            /* 1/13! */
-    q = __builtin_fma(q, y, 1.0 / 479001600.0);
-    q = __builtin_fma(q, y, 1.0 / 39916800.0);
-    q = __builtin_fma(q, y, 1.0 / 3628800.0);
-    q = __builtin_fma(q, y, 1.0 / 362880.0);
-    q = __builtin_fma(q, y, 1.0 / 40320.0);
-    q = __builtin_fma(q, y, 1.0 / 5040.0);
-    q = __builtin_fma(q, y, 1.0 / 720.0);
-    q = __builtin_fma(q, y, 1.0 / 120.0);
-    q = __builtin_fma(q, y, 1.0 / 24.0);
-    q = __builtin_fma(q, y, 1.0 / 6.0);
+    const double fk = __builtin_rint(z * RT_K(1.44269504088896338700e+00));         /* z / ln 2 */
+    double y = __builtin_fma(-fk, RT_K(6.93147180369123816490e-01), z);
+    y = __builtin_fma(-fk, RT_K(1.90821492927058770002e-10), y);
+    double q = RT_K(1.0 / 6227020800.0);                                            /* 1/13! */
+    q = __builtin_fma(q, y, RT_K(1.0 / 479001600.0));
+    q = __builtin_fma(q, y, RT_K(1.0 / 39916800.0));
+    q = __builtin_fma(q, y, RT_K(1.0 / 3628800.0));
+    q = __builtin_fma(q, y, RT_K(1.0 / 362880.0));
+    q = __builtin_fma(q, y, RT_K(1.0 / 40320.0));
+    q = __builtin_fma(q, y, RT_K(1.0 / 5040.0));
+    q = __builtin_fma(q, y, RT_K(1.0 / 720.0));
+    q = __builtin_fma(q, y, RT_K(1.0 / 120.0));
+    q = __builtin_fma(q, y, RT_K(1.0 / 24.0));
+    q = __builtin_fma(q, y, RT_K(1.0 / 6.0));
     q = __builtin_fma(q, y, 0.5);
     q = __builtin_fma(q, y, 1.0);
     q = __builtin_fma(q, y, 1.0);                                             /* exp(y) */
