@@ -145,7 +145,7 @@ struct ShadeParams {
 #define RT_SHADE_ATTR
 #endif
 
-template <bool FRESH, bool STATS>
+template <bool FRESH, bool STATS, bool SPECULAR>
 __global__ void __launch_bounds__(RT_BLOCK) RT_SHADE_ATTR
 rt_shade_kernel(const ShadeParams P)
 {
@@ -154,7 +154,7 @@ rt_shade_kernel(const ShadeParams P)
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-    rt::PathMachine<rt::CounterRng, STATS> pm(P.S, stk, cn);
+    rt::PathMachine<rt::CounterRng, STATS, SPECULAR> pm(P.S, stk, cn);
     pm.half_w = P.half_w; pm.half_h = P.half_h; pm.max_segments = P.max_segments;
     pm.rng.seed0 = P.seed0; pm.rng.seed1 = P.seed1;
     pm.phase = rt::PH_DEAD;
@@ -559,7 +559,7 @@ struct FinishParams {
     float half_w, half_h;
 };
 
-template <bool STATS>
+template <bool STATS, bool SPECULAR>
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_finish_kernel(const FinishParams P)
 {
@@ -567,7 +567,7 @@ rt_finish_kernel(const FinishParams P)
     rt::Stack stk; stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK;
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
     const uint32_t lane = threadIdx.x & 63;
-    rt::PathMachine<rt::CounterRng, STATS> pm(P.S, stk, cn);
+    rt::PathMachine<rt::CounterRng, STATS, SPECULAR> pm(P.S, stk, cn);
     pm.half_w = P.half_w; pm.half_h = P.half_h; pm.max_segments = P.max_segments;
     pm.rng.seed0 = P.seed0; pm.rng.seed1 = P.seed1;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -861,6 +861,7 @@ struct rt_gpu_scene {
     uint32_t *d_parked[2] = {nullptr, nullptr}; uint64_t parked_records = 0;   /* paths in transit, ping-pong */
     QueueCounters *d_queue = nullptr;
     uint32_t shade_blocks = 0, resume_blocks = 0, tree_blocks = 0, finish_blocks = 0;   /* persistent grid sizes */
+    bool specular = true;                                     /* some material is a mirror or glass */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tree_timers;
     double tree_ms = 0.0, fresh_ms = 0.0, finish_ms = 0.0;
     uint64_t overflowed = 0, rounds = 0;
@@ -909,6 +910,20 @@ static void build_aes_table(uint32_t table[256])
         table[x] = (uint32_t)mulg(s, 14) | ((uint32_t)mulg(s, 9) << 8) | ((uint32_t)mulg(s, 13) << 16) |
                    ((uint32_t)mulg(s, 11) << 24);
     }
+}
+
+/* the shade kernel instantiation for (new paths?, detailed counters?, scene has mirror or glass?) */
+template <bool FRESH, bool STATS>
+static void launch_shade_for(bool specular, uint32_t grid, hipStream_t stream, const ShadeParams &P)
+{
+    const size_t lds = FRESH ? 0 : RT_STAGE_LDS;
+    if (specular) hipLaunchKernelGGL((rt_shade_kernel<FRESH, STATS, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, P);
+    else hipLaunchKernelGGL((rt_shade_kernel<FRESH, STATS, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, P);
+}
+static void launch_shade(bool fresh, bool detailed, bool specular, uint32_t grid, hipStream_t stream, const ShadeParams &P)
+{
+    if (fresh) { if (detailed) launch_shade_for<true, true>(specular, grid, stream, P); else launch_shade_for<true, false>(specular, grid, stream, P); }
+    else { if (detailed) launch_shade_for<false, true>(specular, grid, stream, P); else launch_shade_for<false, false>(specular, grid, stream, P); }
 }
 
 extern "C" {
@@ -964,6 +979,14 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
         s->dev.plane_count = (int32_t)flat.planes.size();
         s->dev.instance_count = (int32_t)flat.instances.size();
         s->dev.material_count = (int32_t)flat.materials.size();
+        {   /* does any primitive use a mirror or glass material?  (the table may list materials nothing uses) */
+            auto is_specular = [&](int32_t id) { return id >= 0 && (size_t)id < flat.materials.size() && flat.materials[(size_t)id].kind != 0u; };
+            bool any = false;
+            for (const auto &x : flat.spheres) any = any || is_specular(x.material);
+            for (const auto &x : flat.planes) any = any || is_specular(x.material);
+            for (const auto &x : flat.instances) any = any || is_specular(x.material);
+            s->specular = any;
+        }
         s->dev.texture_count = (int32_t)flat.textures.size();
         s->dev.stack_cap = flat.stack_cap;
         if ((rc = upload(s, flat.lights, &s->dev.lights))) break;
@@ -988,13 +1011,13 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
         {   /* persistent grids: as many workgroups as the device keeps resident */
             const size_t lds_bytes = (size_t)RT_BLOCK * flat.stack_cap * 4;
             int per_cu_shade = 0, per_cu_tree = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, rt_shade_kernel<true, false>, RT_BLOCK, 0) != hipSuccess || per_cu_shade < 1) per_cu_shade = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, rt_shade_kernel<true, false, true>, RT_BLOCK, 0) != hipSuccess || per_cu_shade < 1) per_cu_shade = 1;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tree, rt_tree_kernel<false>, RT_BLOCK, lds_bytes + RT_TREE_EXTRA_LDS) != hipSuccess || per_cu_tree < 1) per_cu_tree = 1;
             int per_cu_finish = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_finish, rt_finish_kernel<false>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_finish < 1) per_cu_finish = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_finish, rt_finish_kernel<false, true>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_finish < 1) per_cu_finish = 1;
             s->finish_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_finish);
             int per_cu_resume = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_resume, rt_shade_kernel<false, false>, RT_BLOCK, RT_STAGE_LDS) != hipSuccess || per_cu_resume < 1) per_cu_resume = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_resume, rt_shade_kernel<false, false, true>, RT_BLOCK, RT_STAGE_LDS) != hipSuccess || per_cu_resume < 1) per_cu_resume = 1;
             s->resume_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_resume);
             s->shade_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_shade);
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
@@ -1207,13 +1230,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
             }
             hipEvent_t e0 = take_event(s), e1 = take_event(s);
             if (e0 && e1) RT_HIP(hipEventRecord(e0, stream));
-            if (round == 0) {
-                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<true, true>), dim3(grid), dim3(RT_BLOCK), 0, stream, P);
-                else hipLaunchKernelGGL((rt_shade_kernel<true, false>), dim3(grid), dim3(RT_BLOCK), 0, stream, P);
-            } else {
-                if (detailed) hipLaunchKernelGGL((rt_shade_kernel<false, true>), dim3(grid), dim3(RT_BLOCK), RT_STAGE_LDS, stream, P);
-                else hipLaunchKernelGGL((rt_shade_kernel<false, false>), dim3(grid), dim3(RT_BLOCK), RT_STAGE_LDS, stream, P);
-            }
+            launch_shade(round == 0, detailed, s->specular, grid, stream, P);
             RT_HIP(hipGetLastError());
             if (e0 && e1) { RT_HIP(hipEventRecord(e1, stream)); s->timers.push_back({e0, e1, round == 0 ? 1 : 0}); }
             QueueCounters qc;
@@ -1254,8 +1271,13 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
                 if (fgrid > s->finish_blocks) fgrid = s->finish_blocks;
                 hipEvent_t f0 = take_event(s), f1 = take_event(s);
                 if (f0 && f1) RT_HIP(hipEventRecord(f0, stream));
-                if (detailed) hipLaunchKernelGGL(rt_finish_kernel<true>, dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
-                else hipLaunchKernelGGL(rt_finish_kernel<false>, dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
+                if (detailed) {
+                    if (s->specular) hipLaunchKernelGGL((rt_finish_kernel<true, true>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
+                    else hipLaunchKernelGGL((rt_finish_kernel<true, false>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
+                } else {
+                    if (s->specular) hipLaunchKernelGGL((rt_finish_kernel<false, true>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
+                    else hipLaunchKernelGGL((rt_finish_kernel<false, false>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
+                }
                 RT_HIP(hipGetLastError());
                 if (f0 && f1) { RT_HIP(hipEventRecord(f1, stream)); s->timers.push_back({f0, f1, 2}); }
                 break;

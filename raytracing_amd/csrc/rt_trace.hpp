@@ -709,7 +709,9 @@ enum : int { PH_SHADE = 0, PH_SCAN = 1, PH_TREE = 2, PH_DEAD = 3, PH_PARK = 4 };
  * 39 index of the sample's slot in the sample scratch. */
 #define RT_RECORD_WORDS 48
 
-template <class Rng, bool STATS>
+/* SPECULAR = false compiles the mirror and glass branches out: for scenes without such materials
+ * (the host checks), whose kernels then carry neither their code nor their registers. */
+template <class Rng, bool STATS, bool SPECULAR = true>
 struct PathMachine {
     const rt_dev_scene &S;
     Stack stk;
@@ -795,14 +797,14 @@ struct PathMachine {
                 Surface sf;
                 surface_of<STATS>(S, o, d, h, sf, cn);
                 const rt_dev_material &m = S.materials[h.material];
-                if (m.kind == 1u) {                                       /* mirror, src/main.c:644-653 */
+                if (SPECULAR && m.kind == 1u) {                           /* mirror, src/main.c:644-653 */
                     throughput = mul(throughput, ld3(m.mirror_color));
                     f3 along = scale(sf.n, dot(sf.n, d));
                     f3 across = sub(d, along);
                     o = sf.p;
                     d = sub(across, scale(along, 2.0f));                  /* unnormalised on purpose */
                     if (segment_budget_left()) ev = EV_TRACE_ONLY; else ended = true;
-                } else if (m.kind == 2u) {                                /* glass, src/main.c:654-674 */
+                } else if (SPECULAR && m.kind == 2u) {                    /* glass, src/main.c:654-674 */
                     f3 along = scale(sf.n, dot(sf.n, d));
                     f3 across = sub(d, along);
                     float ratio = inside_glass ? m.ior : (1.0f / m.ior);
