@@ -331,16 +331,16 @@ def main():
                 "kernel": "rt_shade_kernel + rt_tree_kernel + rt_finish_kernel, all launches of one frame",
                 "kernel_ms": round(kernel_ms, 3),
                 "kernels": {
-                    "rt_shade_kernel<true, false> (new paths)": {
+                    "rt_shade_kernel<true, false, *> (new paths)": {
                         "ms_per_frame": round(fresh_ms, 3), "launches_per_frame": 1,
                         "avg_launch_ms": round(fresh_ms, 3)},
-                    "rt_shade_kernel<false, false> (resumed paths)": {
+                    "rt_shade_kernel<false, false, *> (resumed paths)": {
                         "ms_per_frame": round(resume_ms, 3), "launches_per_frame": round(resume_launches, 2),
                         "avg_launch_ms": round(resume_ms / max(1.0, resume_launches), 4)},
                     "rt_tree_kernel<false>": {
                         "ms_per_frame": round(tree_ms, 3), "launches_per_frame": round(resume_launches, 2),
                         "avg_launch_ms": round(tree_ms / max(1.0, resume_launches), 4)},
-                    "rt_finish_kernel<false> (last paths, shading and trees in one launch)": {
+                    "rt_finish_kernel<false, *> (last paths, shading and trees in one launch)": {
                         "ms_per_frame": round(finish_ms, 3), "launches_per_frame": 1,
                         "avg_launch_ms": round(finish_ms, 3)},
                 },

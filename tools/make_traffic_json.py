@@ -3,7 +3,7 @@
 `bench.py --steps 1 --warmup 0 --no-cpu-baseline --frames-in-flight 1`.  That command renders
 several plain frames and one with the detailed counters (kernel instantiations <..., true>); the
 plain frames' kernels are summed and divided by the number of plain frames (= dispatches of
-rt_shade_kernel<true, false>, one per frame).  usage: make_traffic_json.py FETCH.csv WRITE.csv TAG"""
+the rt_shade_kernel<true, ...> instantiation, one per frame).  usage: make_traffic_json.py FETCH.csv WRITE.csv TAG"""
 import csv, json, sys
 
 def per_kernel(path, counter):
@@ -12,14 +12,18 @@ def per_kernel(path, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        if "rt_" not in name or "true>" in name.replace("<true, false>", ""):
-            continue                                   # not ours, or the detailed-counter frame
+        if "rt_" not in name:
+            continue
         key = name.split("(")[0].replace("void ", "")
+        args = [a.strip() for a in key[key.index("<") + 1:key.rindex(">")].split(",")] if "<" in key else []
+        stats_arg = 1 if key.startswith("rt_shade_kernel") else 0      # position of the detailed-counters flag
+        if args and args[stats_arg] == "true":
+            continue                                   # the frame with detailed counters
         out.setdefault(key, []).append(float(r["Counter_Value"]) * 1024.0)
     return out
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-frames = len(fetch["rt_shade_kernel<true, false>"])
+frames = len(next(v for k, v in fetch.items() if k.startswith("rt_shade_kernel<true,")))
 kernels = {}
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, []), write.get(k, [])
