@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--rehearse-ranks", type=int, default=0,
                     help="single process, single GPU: act as rank 0 of this many ranks and render the other ranks' "
                          "shares in place of the all-gather (a check of the multi-GPU path, not a measurement)")
+    ap.add_argument("--split", choices=("bands", "samples"), default="bands",
+                    help="how N devices share a frame: 8-row bands (bit-identical to one device) or sample ranges of "
+                         "every pixel, summed in rank order (equal up to float summation order; for small frames)")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="frames rendered concurrently (each with its own stream and device work lists)")
     args = ap.parse_args()
@@ -152,11 +155,17 @@ def main():
                 out[:rows].copy_(mine)
                 part = torch.empty_like(mine)
                 for r in range(1, world):
-                    o = gpu.Options(max_segments=args.max_segments, band_rows=multi_gpu.BAND_ROWS, band_rank=r,
-                                    band_count=world, flags=gpu.FLAG_COMPACT_BANDS)
+                    count = args.spp
+                    if args.split == "samples":
+                        first, count = multi_gpu.sample_range(r, world, args.spp)
+                        o = gpu.Options(max_segments=args.max_segments, sample_offset=first, flags=gpu.FLAG_ACCUMULATE)
+                        part.zero_()
+                    else:
+                        o = gpu.Options(max_segments=args.max_segments, band_rows=multi_gpu.BAND_ROWS, band_rank=r,
+                                        band_count=world, flags=gpu.FLAG_COMPACT_BANDS)
                     torch.cuda.synchronize()
                     self.scene.render_region_device(part.data_ptr(), args.width, args.height,
-                                                    (0, 0, args.width, args.height), args.spp, self.seed, o)
+                                                    (0, 0, args.width, args.height), count, self.seed, o)
                     torch.cuda.synchronize()
                     out[r * rows:(r + 1) * rows].copy_(part)
 
@@ -174,6 +183,8 @@ def main():
     band = multi_gpu.BAND_ROWS
     sh = scenes.CONFIGS[args.scene]()
     in_flight = max(1, args.frames_in_flight)
+    by_samples = world > 1 and args.split == "samples"
+    my_spp = spp
 
     # One "lane" per frame in flight: its own resident scene (with its own work lists on the device),
     # stream and output buffers.  Frames are rendered by worker threads (the C call releases the GIL),
@@ -187,14 +198,17 @@ def main():
         ln.g = gpu.GpuScene(sh)                        # flatten + upload: outside the timed region
         ln.stream = torch.cuda.Stream()
         if world > 1:
-            rows = multi_gpu.packed_rows(world, H, band)
+            rows = H if by_samples else multi_gpu.packed_rows(world, H, band)
             ln.mine = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")
             ln.gathered = torch.zeros((world * rows, W, 3), dtype=torch.float32, device="cuda")
         else:
             ln.mine = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
             ln.gathered = None
         lanes.append(ln)
-    if world > 1:
+    if by_samples:
+        first_sample, my_spp = multi_gpu.sample_range(rank, world, spp)
+        opts = gpu.Options(max_segments=args.max_segments, sample_offset=first_sample, flags=gpu.FLAG_ACCUMULATE)
+    elif world > 1:
         opts = gpu.Options(max_segments=args.max_segments, band_rows=band, band_rank=rank, band_count=world,
                            flags=gpu.FLAG_COMPACT_BANDS)
     else:
@@ -208,7 +222,10 @@ def main():
 
     def render(ln, seed, options):
         ln.seed = seed
-        ln.g.render_region_device(ln.mine.data_ptr(), W, H, (0, 0, W, H), spp, seed, options, ln.stream.cuda_stream)
+        if by_samples:
+            with torch.cuda.stream(ln.stream):
+                ln.mine.zero_()                        # this rank's samples are added to zeros
+        ln.g.render_region_device(ln.mine.data_ptr(), W, H, (0, 0, W, H), my_spp, seed, options, ln.stream.cuda_stream)
 
     def finish_frame(ln):
         nonlocal frame
@@ -217,7 +234,10 @@ def main():
                 if args.rehearse_ranks > 1:
                     dist.seed = ln.seed
                 dist.all_gather_into_tensor(ln.gathered, ln.mine)
-                frame = multi_gpu.assemble(ln.gathered, world, H, W, band)
+                if by_samples:
+                    frame = multi_gpu.combine_partial_sums(ln.gathered, world, spp)
+                else:
+                    frame = multi_gpu.assemble(ln.gathered, world, H, W, band)
         else:
             frame = ln.mine
 
@@ -276,10 +296,10 @@ def main():
     # algorithmic bytes of ONE frame: the same frame (seed 0) with the detailed counters on, untimed
     g.reset_stats()
     run_frames([0], gpu.Options(max_segments=args.max_segments, flags=opts.flags | gpu.FLAG_DETAILED_STATS,
-                                band_rows=opts.band_rows, band_rank=opts.band_rank, band_count=opts.band_count), depth=1)
+                                sample_offset=opts.sample_offset, band_rows=opts.band_rows, band_rank=opts.band_rank, band_count=opts.band_count), depth=1)
     torch.cuda.synchronize()
     det = g.stats()
-    own_pixels = (H // world) * W
+    own_pixels = H * W if by_samples else (H // world) * W
     shade_bytes, tree_bytes = algorithmic_bytes(det, own_pixels)
     abytes = shade_bytes + tree_bytes
     checksum = float(frame.double().sum().item())
@@ -316,7 +336,8 @@ def main():
                 "rays_per_step": round(rays / args.steps),
                 "rays_per_sample": round(rays / args.steps / (W * H * spp), 3),
                 "ms_per_frame": round(1e3 * elapsed / args.steps, 3),
-                "split": "8-row bands round-robin + all-gather" if world > 1 else "single device",
+                "split": ("sample ranges + all-gather + sum in rank order" if by_samples else
+                          "8-row bands round-robin + all-gather") if world > 1 else "single device",
                 "frames_in_flight": in_flight,
                 "frame_checksum_seed0": checksum,
             },

@@ -33,3 +33,38 @@ def assemble(gathered, world, height, width, band=BAND_ROWS):
     other as all_gather_into_tensor leaves them -> (height, width, 3) in image order."""
     nb = height // (band * world)
     return gathered.view(world, nb, band, width, 3).permute(1, 0, 2, 3, 4).reshape(height, width, 3)
+
+
+# --------------------------------------------------------------------------- split by samples
+#
+# For small frames (few pixels per device) the other natural split is by samples: rank r renders
+# samples [offset, offset + count) of EVERY pixel as un-normalised sums (RT_GPU_FLAG_ACCUMULATE
+# into a zeroed buffer, sample_offset = offset), the partial sums are gathered and added in rank
+# order (the same order on every rank, so all ranks hold identical bits), and the sum is scaled
+# by the reference's final factor (src/main.c:788).  The per-pixel sum is then grouped by rank
+# instead of running sample by sample, so the frame equals the single-device one up to float
+# summation order, not bit for bit; the band split above is the default for that reason.
+
+def sample_range(rank, world, spp):
+    """(first sample, number of samples) of `rank`: an even split, the remainder to the low ranks."""
+    base, extra = divmod(spp, world)
+    count = base + (1 if rank < extra else 0)
+    first = rank * base + min(rank, extra)
+    return first, count
+
+
+def pixel_norm(spp_total):
+    """The reference's final factor 1/(0.5*0.5*2*pi*spp) as it rounds it: the float product 0.5f widened,
+    the rest in double, the quotient narrowed to float (src/main.c:760,788)."""
+    import math
+    import numpy as np
+    return np.float32(1.0 / (0.5 * math.pi * spp_total))
+
+
+def combine_partial_sums(gathered, world, spp_total):
+    """gathered: (world * H, W, 3) partial sums as all_gather_into_tensor leaves them -> (H, W, 3) frame."""
+    parts = gathered.view(world, -1, gathered.shape[-2], 3)
+    total = parts[0].clone()
+    for r in range(1, world):
+        total += parts[r]
+    return total * float(pixel_norm(spp_total))

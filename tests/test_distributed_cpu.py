@@ -70,3 +70,47 @@ def test_rows_of_rank_partition():
             assert all(len(multi_gpu.rows_of_rank(r, world, height)) == height // world for r in range(world))
     with pytest.raises(ValueError):
         multi_gpu.packed_rows(3, 64)
+
+
+def _sum_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    mine = torch.rand((6, 5, 3), generator=g, dtype=torch.float32) * 37.0
+    gathered = torch.zeros((world * 6, 5, 3), dtype=torch.float32)
+    dist.all_gather_into_tensor(gathered, mine)
+    frame = multi_gpu.combine_partial_sums(gathered, world, 64).numpy().copy()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, frame))
+
+
+def test_sample_split_partial_sums_three_ranks():
+    """Split by samples: partial sums gathered and added in rank order give every rank the same bits,
+    equal to the sum taken in that order by hand, times the reference's final factor."""
+    import torch
+    import torch.multiprocessing as mp
+    world = 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sum_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    frames = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    parts = [(torch.rand((6, 5, 3), generator=torch.Generator().manual_seed(100 + r), dtype=torch.float32) * 37.0).numpy()
+             for r in range(world)]
+    want = ((parts[0] + parts[1]) + parts[2]) * multi_gpu.pixel_norm(64)
+    for r in range(world):
+        assert L.same_bits(frames[r], want.astype(np.float32)).all()
+    assert [multi_gpu.sample_range(r, 3, 64) for r in range(3)] == [(0, 22), (22, 21), (43, 21)]
+    assert sum(multi_gpu.sample_range(r, 8, 64)[1] for r in range(8)) == 64
+    assert multi_gpu.pixel_norm(64) == np.float32(1.0 / (0.5 * np.pi * 64))

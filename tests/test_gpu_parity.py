@@ -358,6 +358,32 @@ def test_band_split_is_invisible(gpu_scenes, world):
     assert L.same_bits(multi_gpu.assemble(gathered, world, H, W).cpu().numpy(), whole).all()
 
 
+def test_sample_split_equals_the_frame_up_to_summation_order(gpu_scenes):
+    """The other split over devices: rank r adds samples [first, first + count) of every pixel to zeros,
+    the partial sums are added in rank order and scaled once.  Each partial sum is the oracle's own
+    (same streams, same order within the rank); only the grouping of the per-pixel sum differs from
+    the single-device frame, so the frames agree to a few ulps of the sum (tolerance 2e-6 relative
+    to the pixel, 7 samples), not bit for bit."""
+    import torch
+    from raytracing_amd import multi_gpu
+    sh, gs = gpu_scenes("dog_room")
+    W, H, spp, seed, world = 56, 40, 7, 21, 3
+    whole = oracle_counter(sh, W, H, (0, 0, W, H), spp, seed)
+    gathered = torch.zeros((world * H, W, 3), dtype=torch.float32, device="cuda")
+    for r in range(world):
+        first, count = multi_gpu.sample_range(r, world, spp)
+        o = gpu.Options(flags=gpu.FLAG_ACCUMULATE, sample_offset=first)
+        part = gathered[r * H:(r + 1) * H]
+        gs.render_region_device(part.data_ptr(), W, H, (0, 0, W, H), count, seed, o)
+        torch.cuda.synchronize()
+        # the partial sum, scaled for its own sample count, is the oracle's frame of those samples
+        own = (part * float(multi_gpu.pixel_norm(count))).cpu().numpy()
+        assert L.same_bits(own, oracle_counter(sh, W, H, (0, 0, W, H), count, seed, sample_offset=first)).all()
+    got = multi_gpu.combine_partial_sums(gathered, world, spp).cpu().numpy()
+    assert np.abs(got - whole).max() <= 2e-6 * np.abs(whole).max()
+    assert (np.abs(got - whole) <= 2e-6 * np.maximum(np.abs(whole), 1e-3)).all()
+
+
 # ---------------------------------------------------------------- replay of the reference's own jobs
 
 @pytest.mark.parametrize("name", SCENES)
