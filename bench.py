@@ -47,18 +47,38 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X vector fp32 spec peak (256 CUs x 128 lanes x 2 x 2.4 GHz)
+
+
+def work_model():
+    """The per-event byte and flop constants of include/rt_work_model.h."""
+    import re
+    with open(os.path.join(ROOT, "include", "rt_work_model.h")) as f:
+        return {k: int(v) for k, v in re.findall(r"#define\s+(RT_(?:BYTES|FLOPS)_\w+)\s+(\d+)", f.read())}
 
 
 def algorithmic_bytes(st, pixels):
     """Bytes the reference's records would move for the work the kernels counted, per kernel:
-    Light 32, Sphere 20, Plane 20 per primitive tested; Transform 48 + root box 24 per instance
-    root test; 3 normals + 3 uvs (60) per triangle hit; one 12-byte texel per lookup; one 12-byte
-    pixel store per pixel (shade kernel); two child Mesh_Nodes (2 x 40) per interior pop and
-    Triangle 36 + 3 points 36 per triangle test (tree kernel)."""
-    shade = (32 * st["light_tests"] + 20 * st["sphere_tests"] + 20 * st["plane_tests"] +
-             72 * st["root_tests"] + 60 * st["tri_hits"] + 12 * st["tex_lookups"] + 12 * pixels)
-    tree = 80 * st["interior_pops"] + 72 * st["tri_tests"]
+    lights, spheres, planes, instance root tests, triangle-hit attributes, texels and the pixel store
+    (shade kernel); the two child nodes per interior pop and the triangle with its three points per
+    triangle test (tree kernel)."""
+    m = work_model()
+    shade = (m["RT_BYTES_LIGHT_TEST"] * st["light_tests"] + m["RT_BYTES_SPHERE_TEST"] * st["sphere_tests"] +
+             m["RT_BYTES_PLANE_TEST"] * st["plane_tests"] + m["RT_BYTES_ROOT_TEST"] * st["root_tests"] +
+             m["RT_BYTES_TRI_HIT"] * st["tri_hits"] + m["RT_BYTES_TEX_LOOKUP"] * st["tex_lookups"] +
+             m["RT_BYTES_PIXEL"] * pixels)
+    tree = m["RT_BYTES_INTERIOR_POP"] * st["interior_pops"] + m["RT_BYTES_TRI_TEST"] * st["tri_tests"]
     return shade, tree
+
+
+def algorithmic_flops(st):
+    """Flops of the reference's expressions for the same counted work (transcendentals excluded)."""
+    m = work_model()
+    return (m["RT_FLOPS_LIGHT_TEST"] * st["light_tests"] + m["RT_FLOPS_SPHERE_TEST"] * st["sphere_tests"] +
+            m["RT_FLOPS_PLANE_TEST"] * st["plane_tests"] + m["RT_FLOPS_ROOT_TEST"] * st["root_tests"] +
+            m["RT_FLOPS_INTERIOR_POP"] * st["interior_pops"] + m["RT_FLOPS_TRI_TEST"] * st["tri_tests"] +
+            m["RT_FLOPS_TRI_HIT"] * st["tri_hits"] +
+            m["RT_FLOPS_PATH_SEGMENT"] * (st["rays"] - st["shadow_rays"]))
 
 
 def cpu_baseline(sh, width, height, target_seconds=12.0):
@@ -302,6 +322,7 @@ def main():
     own_pixels = H * W if by_samples else (H // world) * W
     shade_bytes, tree_bytes = algorithmic_bytes(det, own_pixels)
     abytes = shade_bytes + tree_bytes
+    aflops = algorithmic_flops(det)
     checksum = float(frame.double().sum().item())
 
     # HBM bytes per frame as counted by the L2's memory-side request counters in a separate
@@ -370,6 +391,17 @@ def main():
                     "tree nodes and triangles": int(tree_bytes)},
                 "algorithmic_bytes_per_frame": int(abytes),
                 "algorithmic_bytes_per_ray": round(abytes / max(1, det["rays"]), 1),
+                # the roof that binds in practice: every float operation is a separately rounded
+                # vector instruction (no contraction), so a frame is priced against vector fp32 issue too
+                "valu_fp32": {
+                    "achieved": round(aflops / (kernel_ms * 1e-3) / 1e12, 3) if kernel_ms > 0 else 0.0,
+                    "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(aflops / (kernel_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS, 4) if kernel_ms > 0 else 0.0,
+                    "algorithmic_flops_per_frame": int(aflops),
+                    "algorithmic_flops_per_ray": round(aflops / max(1, det["rays"]), 1),
+                    "note": "flops of the reference's expressions (include/rt_work_model.h), one per add, multiply, "
+                            "divide, compare or square root; a correctly rounded divide or square root costs about "
+                            "ten instructions, and the peak counts a fused multiply-add as two"},
                 "counted": {k: int(det[k]) for k in ("rays", "shadow_rays", "root_tests", "interior_pops",
                                                      "tri_tests", "tri_hits", "tex_lookups", "light_tests",
                                                      "sphere_tests", "plane_tests")},

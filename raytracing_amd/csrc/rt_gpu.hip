@@ -121,6 +121,8 @@ struct ShadeParams {
 
 #define RT_STAGE 32u                  /* records per LDS buffer of a resumed-path wave (x 160 bytes, two buffers per wave) */
 #define RT_STAGE_LDS ((size_t)(RT_BLOCK / 64) * 2u * RT_STAGE * 160u)
+#define RT_POOL 128u                  /* first hits of new paths a new-path wave can hold in LDS (3 quads each) */
+#define RT_POOL_LDS ((size_t)(RT_BLOCK / 64) * RT_POOL * 48u)
 #ifndef RT_IN_BATCH
 #define RT_IN_BATCH 256u              /* list slots a resumed-path wave takes per atomic on the shared cursor */
 #endif
@@ -203,43 +205,122 @@ rt_shade_kernel(const ShadeParams P)
     uint32_t out_cur = 0, out_end = 0;                  /* reserved output range */
     uint32_t parked_here = 0;
 
+    /* write the paths of the lanes that `want` it to the parked list (m: the machine holding them) */
+    auto park = [&](bool want, auto &m, uint32_t sidx) {
+        const unsigned long long parking = __ballot(want);
+        if (!parking) return;
+        const uint32_t count = (uint32_t)__popcll(parking);
+        const uint32_t rank = (uint32_t)__popcll(parking & lanes_below);
+        const uint32_t room = out_end - out_cur;
+        uint32_t next_base = 0;
+        if (count > room) {                              /* reserve the next chunk; the old one is filled to its end */
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(&P.q->out_reserved, P.chunk);
+            next_base = __builtin_amdgcn_readfirstlane(v);
+        }
+        if (want) {
+            uint32_t slot = rank < room ? out_cur + rank : next_base + (rank - room);
+            if (slot < P.out_capacity) {
+                m.store_record(P.out_list + (size_t)slot * RT_RECORD_WORDS, sidx);
+            } else {                                      /* cannot happen: the host sizes the lists for every path of the launch */
+                atomicAdd(&P.q->overflow, 1u);
+            }
+        }
+        if (count > room) { out_cur = next_base + (count - room); out_end = next_base + P.chunk; }
+        else out_cur += count;
+        parked_here += count;
+    };
+
+    /* New paths (FRESH).  The first event of a path (camera ray, its test against the lights,
+     * spheres and planes, the instance root boxes) is the same code for every path, so it runs for
+     * 64 new paths at once, on all lanes, whatever the lanes' own paths are doing: their state
+     * stays in its registers, the step works in temporaries.  A ray that enters a root box goes
+     * to the parked list right away; the other paths wait in an LDS pool (pixel, direction, first
+     * hit, generator key: 3 quads; quad q of entry i at pool[q * RT_POOL + i]) until a lane is free
+     * to carry them on.  So the lanes' own steps only ever mix the three kinds of step of a path
+     * under way, and those follow each other in a cycle that keeps the lanes together. */
+    uint32_t pool_n = 0;
+    uint4 *pool = reinterpret_cast<uint4 *>(lds) + (threadIdx.x >> 6) * (3u * RT_POOL);
+    auto camera_step = [&]() {
+        if (item_next >= unit_items) {                   /* next portion */
+            uint32_t u = 0;
+            if (lane == 0) u = atomicAdd(&P.q->unit_next, 1u);
+            u = __builtin_amdgcn_readfirstlane(u);
+            if (u >= units * parts) { input_done = true; return; }
+            unit = u / parts;
+            const uint32_t first_spp = (u % parts) * RT_PORTION_SPP;
+            const uint32_t end_spp = first_spp + RT_PORTION_SPP < P.launch_spp ? first_spp + RT_PORTION_SPP : P.launch_spp;
+            item_next = 64u * first_spp; unit_items = 64u * end_spp;
+            bx = unit % P.blocks_x; by = unit / P.blocks_x;
+            if (P.band_blocks) {
+                uint32_t k = by / P.band_blocks, in = by % P.band_blocks;
+                by = (k * P.band_count + P.band_rank) * P.band_blocks + in;
+            }
+        }
+        const uint32_t sample = item_next >> 6;          /* one sample of the block's 64 pixels per step */
+        item_next += 64u;
+        const uint32_t lx = bx * 8 + (lane & 7), ly = by * 8 + (lane >> 3);
+        const uint32_t sidx = (sample * units + unit) * 64u + lane;
+        rt::PathMachine<rt::CounterRng, STATS, SPECULAR> cam(P.S, stk, cn);
+        bool to_park = false, to_pool = false;
+        if (lx < P.w && ly < P.h) {
+            cam.half_w = P.half_w; cam.half_h = P.half_h; cam.max_segments = P.max_segments;
+            cam.rng.seed0 = P.seed0; cam.rng.seed1 = P.seed1;
+            cam.x = P.x0 + lx; cam.y = P.y0 + ly;
+            cam.start_path();
+            cam.rng.begin(P.width * cam.y + cam.x, P.sample_offset + P.first_sample + sample);
+            cam.n = cam.albedo = cam.direct = rt::mk(0, 0, 0);
+            cam.reached_here = cam.shadow_len2 = cam.shadow_cos = 0;
+            cam.li = 0;
+            float tmax;
+            (void)cam.event(tmax);                       /* the camera event never ends a path */
+            cam.park_inst = -1;
+            if (!rt::query_begin<STATS>(P.S, cam.o, cam.d, tmax, false, cam.h, cn))
+                cam.park_inst = rt::query_probe<STATS>(P.S, cam.o, cam.d, cam.h, 0, cn);
+            to_park = cam.park_inst >= 0;
+            to_pool = !to_park;
+        }
+        park(to_park, cam, sidx);
+        const unsigned long long pushing = __ballot(to_pool);
+        if (to_pool) {
+            const uint32_t e = pool_n + (uint32_t)__popcll(pushing & lanes_below);
+            pool[e] = make_uint4(cam.x | (cam.y << 16), sidx, __float_as_uint(cam.d.x), __float_as_uint(cam.d.y));
+            pool[RT_POOL + e] = make_uint4(__float_as_uint(cam.d.z), __float_as_uint(cam.h.t), (uint32_t)cam.h.type, cam.h.id);
+            pool[2u * RT_POOL + e] = make_uint4((uint32_t)cam.h.material, cam.rng.k0, cam.rng.k1, 0u);
+        }
+        pool_n += (uint32_t)__popcll(pushing);
+    };
+
     for (;;) {
         /* ---- 1. give free lanes a path ----------------------------------------- */
-        while (!input_done) {
+        if (FRESH) {
+            const unsigned long long need = __ballot(!has);
+            const uint32_t want = (uint32_t)__popcll(need);
+            if (want) {
+                while (pool_n < want && !input_done) camera_step();   /* always 64 new paths: the pool holds < 64 + 64 */
+                const uint32_t take = want < pool_n ? want : pool_n;
+                const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
+                if (!has && rank < take) {
+                    const uint32_t e = pool_n - 1u - rank;
+                    const uint4 a = pool[e], b = pool[RT_POOL + e], c = pool[2u * RT_POOL + e];
+                    pm.start_path();
+                    pm.x = a.x & 0xFFFFu; pm.y = a.x >> 16;
+                    sample_index = a.y;
+                    pm.o = rt::ld3(P.S.cam.pos);
+                    pm.d = rt::mk(__uint_as_float(a.z), __uint_as_float(a.w), __uint_as_float(b.x));
+                    pm.h.t = __uint_as_float(b.y); pm.h.type = (int)b.z; pm.h.id = b.w; pm.h.inst = 0;
+                    pm.h.beta = 0.0f; pm.h.gamma = 0.0f; pm.h.material = (int)c.x; pm.h.entered = false;
+                    pm.rng.k0 = c.y; pm.rng.k1 = c.z; pm.rng.c0 = 1u; pm.rng.c1 = 0u; pm.rng.fresh = false;
+                    pm.ray = rt::RAY_SEGMENT;            /* the first hit is there to be booked */
+                    has = true;
+                }
+                pool_n -= take;
+            }
+        }
+        while (!FRESH && !input_done) {
             const unsigned long long need = __ballot(!has);
             if (!need) break;
-            if (FRESH) {
-                if (item_next >= unit_items) {           /* next portion */
-                    uint32_t u = 0;
-                    if (lane == 0) u = atomicAdd(&P.q->unit_next, 1u);
-                    u = __builtin_amdgcn_readfirstlane(u);
-                    if (u >= units * parts) { input_done = true; break; }
-                    unit = u / parts;
-                    const uint32_t first_spp = (u % parts) * RT_PORTION_SPP;
-                    const uint32_t end_spp = first_spp + RT_PORTION_SPP < P.launch_spp ? first_spp + RT_PORTION_SPP : P.launch_spp;
-                    item_next = 64u * first_spp; unit_items = 64u * end_spp;
-                    bx = unit % P.blocks_x; by = unit / P.blocks_x;
-                    if (P.band_blocks) {
-                        uint32_t k = by / P.band_blocks, in = by % P.band_blocks;
-                        by = (k * P.band_count + P.band_rank) * P.band_blocks + in;
-                    }
-                }
-                const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
-                const uint32_t item = item_next + rank;
-                if (!has && item < unit_items) {
-                    const uint32_t p = item & 63u;
-                    const uint32_t lx = bx * 8 + (p & 7), ly = by * 8 + (p >> 3);
-                    if (lx < P.w && ly < P.h) {
-                        pm.x = P.x0 + lx; pm.y = P.y0 + ly;
-                        pm.start_path();
-                        pm.rng.begin(P.width * pm.y + pm.x, P.sample_offset + P.first_sample + (item >> 6));
-                        sample_index = ((item >> 6) * units + unit) * 64u + p;
-                        has = true;
-                    }
-                }
-                item_next += (uint32_t)__popcll(need);
-                if (item_next > unit_items) item_next = unit_items;
-            } else {
+            {
                 /* Records reach the lanes through two LDS buffers of RT_STAGE slots each, filled straight
                  * from the list (global_load_lds: no registers, nothing to wait for at issue).  While
                  * the lanes take records from one buffer the other is on its way, so the fetch of a
@@ -263,14 +344,14 @@ rt_shade_kernel(const ShadeParams P)
 
         /* ---- 2. one shade step ---------------------------------------------------- */
         /* Lanes about to do the same kind of step run together: a step's cost is dominated by the
-         * code of its kind (book a surface hit / book a light sample, then a camera, light-sample
-         * or bounce event), and a wave pays for every kind that any active lane takes.  The kind
-         * most lanes want runs; the others keep their state and wait to become the majority
-         * (kinds follow each other in a cycle, so waiting lanes are soon joined). */
+         * code of its kind (book a surface hit / book a light sample, then a light-sample or bounce
+         * event), and a wave pays for every kind that any active lane takes.  The kind most lanes
+         * want runs; the others keep their state and wait to become the majority (kinds follow
+         * each other in a cycle, so waiting lanes are soon joined). */
         bool go = has;
 #if RT_SHADE_CLASSES
         {
-            int kind = 0;                                 /* new path: camera event */
+            int kind = 0;                                 /* a path about to start (AES replay and finishing launch only) */
             if (pm.ray == rt::RAY_SEGMENT) kind = 1;      /* book a surface hit, then usually the first light sample */
             else if (pm.ev == rt::EV_NEE) kind = (pm.li + 1 < P.S.light_count) ? 2 : 3;   /* next light sample / bounce */
             const int n0 = __popcll(__ballot(has && kind == 0)), n1 = __popcll(__ballot(has && kind == 1));
@@ -294,31 +375,9 @@ rt_shade_kernel(const ShadeParams P)
         }
 
         /* ---- 3. park the lanes whose ray has to walk a tree ------------------------- */
-        const unsigned long long parking = __ballot(has && pm.phase == rt::PH_PARK);
-        if (parking) {
-            const uint32_t count = (uint32_t)__popcll(parking);
-            const uint32_t rank = (uint32_t)__popcll(parking & lanes_below);
-            const uint32_t room = out_end - out_cur;
-            uint32_t next_base = 0;
-            if (count > room) {                          /* reserve the next chunk; the old one is filled to its end */
-                uint32_t v = 0;
-                if (lane == 0) v = atomicAdd(&P.q->out_reserved, P.chunk);
-                next_base = __builtin_amdgcn_readfirstlane(v);
-            }
-            if (has && pm.phase == rt::PH_PARK) {
-                uint32_t slot = rank < room ? out_cur + rank : next_base + (rank - room);
-                if (slot < P.out_capacity) {
-                    pm.store_record(P.out_list + (size_t)slot * RT_RECORD_WORDS, sample_index);
-                } else {                                  /* cannot happen: the host sizes the lists for every path of the launch */
-                    atomicAdd(&P.q->overflow, 1u);
-                }
-                has = false;
-                pm.phase = rt::PH_DEAD;
-            }
-            if (count > room) { out_cur = next_base + (count - room); out_end = next_base + P.chunk; }
-            else out_cur += count;
-            parked_here += count;
-        }
+        const bool parks = has && pm.phase == rt::PH_PARK;
+        park(parks, pm, sample_index);
+        if (parks) { has = false; pm.phase = rt::PH_DEAD; }
     }
     /* unused tail of the last reserved chunk: mark the slots empty */
     for (uint32_t slot = out_cur + lane; slot < out_end && slot < P.out_capacity; slot += 64)
@@ -916,7 +975,7 @@ static void build_aes_table(uint32_t table[256])
 template <bool FRESH, bool STATS>
 static void launch_shade_for(bool specular, uint32_t grid, hipStream_t stream, const ShadeParams &P)
 {
-    const size_t lds = FRESH ? 0 : RT_STAGE_LDS;
+    const size_t lds = FRESH ? RT_POOL_LDS : RT_STAGE_LDS;
     if (specular) hipLaunchKernelGGL((rt_shade_kernel<FRESH, STATS, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, P);
     else hipLaunchKernelGGL((rt_shade_kernel<FRESH, STATS, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, P);
 }
@@ -1011,7 +1070,7 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
         {   /* persistent grids: as many workgroups as the device keeps resident */
             const size_t lds_bytes = (size_t)RT_BLOCK * flat.stack_cap * 4;
             int per_cu_shade = 0, per_cu_tree = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, rt_shade_kernel<true, false, true>, RT_BLOCK, 0) != hipSuccess || per_cu_shade < 1) per_cu_shade = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, rt_shade_kernel<true, false, true>, RT_BLOCK, RT_POOL_LDS) != hipSuccess || per_cu_shade < 1) per_cu_shade = 1;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tree, rt_tree_kernel<false>, RT_BLOCK, lds_bytes + RT_TREE_EXTRA_LDS) != hipSuccess || per_cu_tree < 1) per_cu_tree = 1;
             int per_cu_finish = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_finish, rt_finish_kernel<false, true>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_finish < 1) per_cu_finish = 1;
