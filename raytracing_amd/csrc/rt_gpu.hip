@@ -110,6 +110,7 @@ struct ShadeParams {
     uint32_t *out_list;              /* records this launch parks */
     uint32_t in_slots, out_capacity;
     uint32_t chunk;                  /* output slots a wave reserves per atomic (<= RT_CHUNK, multiple of 64) */
+    uint32_t tail_lanes;             /* a wave left with fewer paths than this and no input hands them to the next round (0: never) */
     uint32_t width, height;          /* image */
     uint32_t x0, y0, w, h;           /* region */
     uint32_t blocks_x, block_rows;   /* units = 8x8 pixel blocks of this launch */
@@ -119,8 +120,11 @@ struct ShadeParams {
     float    half_w, half_h;
 };
 
-#define RT_STAGE 32u                  /* records per LDS buffer of a resumed-path wave (x 160 bytes, two buffers per wave) */
-#define RT_STAGE_LDS ((size_t)(RT_BLOCK / 64) * 2u * RT_STAGE * 160u)
+#define RT_STAGE_WORDS (64u * 40u + 64u)   /* LDS words of a resumed-path wave: 64 record slots of 10 quads + 64 slot numbers */
+#define RT_STAGE_LDS ((size_t)(RT_BLOCK / 64) * RT_STAGE_WORDS * 4u)
+#ifndef RT_STAGE_REFILL
+#define RT_STAGE_REFILL 16            /* empty record slots that make a resumed-path wave fetch more of the list */
+#endif
 #define RT_POOL 128u                  /* first hits of new paths a new-path wave can hold in LDS (3 quads each) */
 #define RT_POOL_LDS ((size_t)(RT_BLOCK / 64) * RT_POOL * 48u)
 #ifndef RT_IN_BATCH
@@ -133,8 +137,14 @@ struct ShadeParams {
 #define RT_PORTION_SPP 8u             /* samples per pixel in one portion of fresh work (x 64 pixels) */
 #endif
 #ifndef RT_SHADE_CLASSES
-#define RT_SHADE_CLASSES 1            /* 1: per iteration only the lanes of the most wanted kind of step run */
+#define RT_SHADE_CLASSES 1            /* new paths: 1: per iteration only the lanes of the most wanted kind of step run;
+                                       * 2: the two kinds that book a light sample count as one; 0: all lanes run */
 #endif
+#ifndef RT_RESUME_CLASSES
+#define RT_RESUME_CLASSES RT_SHADE_CLASSES   /* the same for resumed paths */
+#endif
+#define RT_KIND_CLASS(fresh, k) (((fresh) ? RT_SHADE_CLASSES : RT_RESUME_CLASSES) == 0 ? 1 : \
+                                 ((fresh) ? RT_SHADE_CLASSES : RT_RESUME_CLASSES) == 2 && (k) == 3 ? 2 : (k))
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4              /* waves per SIMD the shade kernel is compiled for (0: compiler's choice) */
 #endif
@@ -172,12 +182,18 @@ rt_shade_kernel(const ShadeParams P)
     uint32_t bx = 0, by = 0;
     uint32_t in_cur = 0, in_end = 0;                    /* resume: slots taken from the shared cursor, not yet staged */
     bool cursor_done = false;
-    uint32_t buf_n[2] = {0u, 0u}, use_b = 0, use_pos = 0;   /* resume: records in each LDS buffer; buffer and position being read */
     bool input_done = false;
     extern __shared__ uint32_t lds[];
-    uint32_t *stage = lds + (threadIdx.x >> 6) * (2u * RT_STAGE * 40u);      /* per wave: 2 buffers x RT_STAGE records x 10 quads,
-                                                                               * quad q of slot i at word (q * RT_STAGE + i) * 4 */
-    auto stage_into = [&](uint32_t b) {                  /* request the next RT_STAGE slots of the list into buffer b */
+    /* Resumed paths: records come from the list through 64 LDS slots per wave (slot j is filled by
+     * lane j with global_load_lds: no registers, nothing to wait for at issue; quad q of slot j at
+     * word (q * 64 + j) * 4).  A record's kind of next step is known before a lane takes it, so a
+     * free lane takes a record of the kind the wave is about to run: the lanes stay together. */
+    uint32_t *stage = lds + (threadIdx.x >> 6) * RT_STAGE_WORDS;
+    uint32_t *pick = stage + 64u * 40u;                 /* slot numbers handed to the free lanes */
+    unsigned long long ready = 0, flight = 0;           /* slots holding a record / being filled */
+    int slot_kind = 0;                                  /* kind of the record in slot `lane` */
+    auto stage_issue = [&]() {                           /* fill the empty slots from the list */
+        const unsigned long long empty = ~(ready | flight);
         if (in_cur >= in_end && !cursor_done) {
             uint32_t v = 0;
             if (lane == 0) v = atomicAdd(&P.q->in_next, RT_IN_BATCH);
@@ -185,28 +201,39 @@ rt_shade_kernel(const ShadeParams P)
             if (in_cur >= P.in_slots) { cursor_done = true; in_end = in_cur; }
             else in_end = in_cur + RT_IN_BATCH < P.in_slots ? in_cur + RT_IN_BATCH : P.in_slots;
         }
-        const uint32_t n = in_end - in_cur < RT_STAGE ? in_end - in_cur : RT_STAGE;
-        if (lane < n) {
-            const uint32_t *src = P.in_list + (size_t)(in_cur + lane) * RT_RECORD_WORDS;
-            uint32_t *dst = stage + b * (RT_STAGE * 40u);
+        const uint32_t room = (uint32_t)__popcll(empty);
+        const uint32_t n = in_end - in_cur < room ? in_end - in_cur : room;
+        const uint32_t rank = (uint32_t)__popcll(empty & lanes_below);
+        const bool mine = ((empty >> lane) & 1ull) && rank < n;
+        if (mine) {
+            const uint32_t *src = P.in_list + (size_t)(in_cur + rank) * RT_RECORD_WORDS;
 #pragma unroll
             for (uint32_t qd = 0; qd < 10u; qd++)
-                __builtin_amdgcn_global_load_lds(src + 4u * qd, dst + 4u * RT_STAGE * qd, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(src + 4u * qd, stage + 4u * 64u * qd, 16, 0, 0);
         }
-        buf_n[b] = n;
+        flight |= __ballot(mine);
         in_cur += n;
     };
-    if (!FRESH) {                                        /* fill both buffers; reading starts with buffer 1 */
-        stage_into(1u);
-        stage_into(0u);
+    auto stage_land = [&]() {                            /* the slots being filled have their records: look at them */
+        if (!flight) return;
         __builtin_amdgcn_s_waitcnt(0x0F70);              /* vmcnt(0) */
-        use_b = 1u; use_pos = 0;
-    }
+        bool ok = false;
+        if ((flight >> lane) & 1ull) {
+            const uint32_t f = stage[lane * 4u], w = stage[(3u * 64u + lane) * 4u + 3u];
+            const int ev = (int)((f >> 1) & 3u), ray = (int)((f >> 3) & 3u), li = (int)(w >> 16);
+            slot_kind = ray == rt::RAY_SEGMENT ? 1 : (ev == rt::EV_NEE ? (li + 1 < P.S.light_count ? 2 : 3) : 0);
+            slot_kind = RT_KIND_CLASS(false, slot_kind);
+            ok = (f & 1u) != 0u;                         /* padding of the list: no record */
+        }
+        ready |= __ballot(ok);
+        flight = 0;
+    };
+    if (!FRESH) { stage_issue(); stage_land(); stage_issue(); }
     uint32_t out_cur = 0, out_end = 0;                  /* reserved output range */
     uint32_t parked_here = 0;
 
     /* write the paths of the lanes that `want` it to the parked list (m: the machine holding them) */
-    auto park = [&](bool want, auto &m, uint32_t sidx) {
+    auto park = [&](bool want, auto &m, uint32_t sidx, bool ready_flag = false) {
         const unsigned long long parking = __ballot(want);
         if (!parking) return;
         const uint32_t count = (uint32_t)__popcll(parking);
@@ -221,7 +248,7 @@ rt_shade_kernel(const ShadeParams P)
         if (want) {
             uint32_t slot = rank < room ? out_cur + rank : next_base + (rank - room);
             if (slot < P.out_capacity) {
-                m.store_record(P.out_list + (size_t)slot * RT_RECORD_WORDS, sidx);
+                m.store_record(P.out_list + (size_t)slot * RT_RECORD_WORDS, sidx, ready_flag);
             } else {                                      /* cannot happen: the host sizes the lists for every path of the launch */
                 atomicAdd(&P.q->overflow, 1u);
             }
@@ -317,52 +344,62 @@ rt_shade_kernel(const ShadeParams P)
                 pool_n -= take;
             }
         }
-        while (!FRESH && !input_done) {
-            const unsigned long long need = __ballot(!has);
-            if (!need) break;
-            {
-                /* Records reach the lanes through two LDS buffers of RT_STAGE slots each, filled straight
-                 * from the list (global_load_lds: no registers, nothing to wait for at issue).  While
-                 * the lanes take records from one buffer the other is on its way, so the fetch of a
-                 * record is a full buffer ahead of its use. */
-                if (use_pos >= buf_n[use_b]) {
-                    if (buf_n[use_b ^ 1u] == 0u) { input_done = true; break; }   /* nothing staged, nothing left to stage */
-                    __builtin_amdgcn_s_waitcnt(0x0F70);  /* vmcnt(0): the other buffer has landed */
-                    stage_into(use_b);
-                    use_b ^= 1u; use_pos = 0;
-                }
-                const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
-                const uint32_t idx = use_pos + rank;
-                if (!has && idx < buf_n[use_b])
-                    has = pm.load_record(reinterpret_cast<const uint4 *>(stage + use_b * (RT_STAGE * 40u)) + idx, RT_STAGE, sample_index);
-                use_pos += (uint32_t)__popcll(need);
-                if (use_pos > buf_n[use_b]) use_pos = buf_n[use_b];
-            }
-            if (__ballot(has) == ~0ull) break;
-        }
-        if (!__ballot(has)) break;                       /* nothing in flight and no input left */
-
         /* ---- 2. one shade step ---------------------------------------------------- */
         /* Lanes about to do the same kind of step run together: a step's cost is dominated by the
          * code of its kind (book a surface hit / book a light sample, then a light-sample or bounce
-         * event), and a wave pays for every kind that any active lane takes.  The kind most lanes
-         * want runs; the others keep their state and wait to become the majority (kinds follow
-         * each other in a cycle, so waiting lanes are soon joined). */
-        bool go = has;
-#if RT_SHADE_CLASSES
-        {
-            int kind = 0;                                 /* a path about to start (AES replay and finishing launch only) */
+         * event), and a wave pays for every kind that any active lane takes.  The kind that most
+         * lanes want, or could want once free lanes have taken waiting records of that kind, runs;
+         * the others keep their state and wait to become the majority (kinds follow each other in
+         * a cycle, so waiting lanes are soon joined). */
+        auto kind_of = [&]() {
+            int kind = 0;                                 /* a path about to start (never in this kernel) */
             if (pm.ray == rt::RAY_SEGMENT) kind = 1;      /* book a surface hit, then usually the first light sample */
             else if (pm.ev == rt::EV_NEE) kind = (pm.li + 1 < P.S.light_count) ? 2 : 3;   /* next light sample / bounce */
-            const int n0 = __popcll(__ballot(has && kind == 0)), n1 = __popcll(__ballot(has && kind == 1));
-            const int n2 = __popcll(__ballot(has && kind == 2)), n3 = __popcll(__ballot(has && kind == 3));
-            int best = 0, nb = n0;
-            if (n1 > nb) { best = 1; nb = n1; }
-            if (n2 > nb) { best = 2; nb = n2; }
-            if (n3 > nb) { best = 3; nb = n3; }
-            go = has && kind == best;
+            return RT_KIND_CLASS(FRESH, kind);
+        };
+        int best = 0;
+        {
+            const int kind = kind_of();
+            int n[4], a[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; k++) n[k] = __popcll(__ballot(has && kind == k));
+            if (!FRESH) {
+                const int free_lanes = 64 - __popcll(__ballot(has));
+                const bool slot_ready = (ready >> lane) & 1ull;
+#pragma unroll
+                for (int k = 1; k < 4; k++) {
+                    a[k] = __popcll(__ballot(slot_ready && slot_kind == k));
+                    if (a[k] > free_lanes) a[k] = free_lanes;
+                }
+            }
+            int nb = n[0] + a[0];
+#pragma unroll
+            for (int k = 1; k < 4; k++) if (n[k] + a[k] > nb) { best = k; nb = n[k] + a[k]; }
+            if (!FRESH) {
+                if (nb == 0) {                            /* no path in a lane, no record waiting */
+                    if (flight) { stage_land(); continue; }
+                    if (cursor_done && in_cur >= in_end) break;
+                    stage_issue();
+                    continue;
+                }
+                if (a[best]) {                            /* free lanes take the waiting records of that kind */
+                    const unsigned long long slots = __ballot(((ready >> lane) & 1ull) && slot_kind == best);
+                    const unsigned long long need = __ballot(!has);
+                    const uint32_t take = (uint32_t)a[best];
+                    const uint32_t srank = (uint32_t)__popcll(slots & lanes_below);
+                    const bool given = ((slots >> lane) & 1ull) && srank < take;
+                    if (given) pick[srank] = lane;
+                    ready &= ~__ballot(given);
+                    const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
+                    if (!has && rank < take) {
+                        const uint32_t j = pick[rank];
+                        has = pm.load_record(reinterpret_cast<const uint4 *>(stage) + j, 64u, sample_index);
+                    }
+                }
+            }
         }
-#endif
+        if (FRESH && !__ballot(has)) break;              /* nothing in flight and no input left */
+        const bool go = has && kind_of() == best;
         if (STATS) { if (lane == 0) cn.shade_steps++; if (go) cn.shade_lanes++; }
         if (go) {
             pm.shade_step_park([&]() {
@@ -374,10 +411,30 @@ rt_shade_kernel(const ShadeParams P)
             });
         }
 
+        if (!FRESH) {                                    /* what was asked for during the last step has long arrived */
+            stage_land();
+            if (__popcll(~(ready | flight)) >= RT_STAGE_REFILL && !(cursor_done && in_cur >= in_end)) stage_issue();
+        }
+
         /* ---- 3. park the lanes whose ray has to walk a tree ------------------------- */
         const bool parks = has && pm.phase == rt::PH_PARK;
         park(parks, pm, sample_index);
         if (parks) { has = false; pm.phase = rt::PH_DEAD; }
+
+        /* ---- 4. the end of a launch: a few long paths in a few lanes of a few waves.  They make a
+         * better wave together with the next round's paths: a wave that has run out of input and
+         * of most of its paths writes the rest to the list as they are (query complete, nothing
+         * for the tree kernel) and ends.  The wave has just made a step, so every round advances. */
+        if (P.tail_lanes) {
+            const bool no_input = FRESH ? (input_done && pool_n == 0u)
+                                        : (cursor_done && in_cur >= in_end && !ready && !flight);
+            const unsigned long long left = __ballot(has);
+            if (no_input && left && (uint32_t)__popcll(left) < P.tail_lanes) {
+                park(has, pm, sample_index, true);
+                has = false; pm.phase = rt::PH_DEAD;
+                break;
+            }
+        }
     }
     /* unused tail of the last reserved chunk: mark the slots empty */
     for (uint32_t slot = out_cur + lane; slot < out_end && slot < P.out_capacity; slot += 64)
@@ -461,7 +518,7 @@ rt_tree_kernel(const TreeParams P)
             if (!busy && idx < in_end) {
                 const uint4 *q = reinterpret_cast<const uint4 *>(P.list + (size_t)idx * RT_RECORD_WORDS);
                 const uint4 a = q[0], b = q[1], c = q[2], e = q[3];
-                if (a.x & 1u) {
+                if ((a.x & 0x81u) == 1u) {               /* a record, and its query is not complete */
                     slot = idx;
                     any_hit = ((a.x >> 3) & 3u) == (uint32_t)rt::RAY_SHADOW;
                     o = rt::mk(__uint_as_float(a.z), __uint_as_float(a.w), __uint_as_float(b.x));
@@ -655,9 +712,11 @@ rt_finish_kernel(const FinishParams P)
                 const uint32_t idx = in_cur + (uint32_t)__popcll(need & lanes_below);
                 if (pm.phase == rt::PH_DEAD && idx < in_end &&
                     pm.load_record(P.list + (size_t)idx * RT_RECORD_WORDS, sample_index)) {
-                    pm.tv.inst = (int)(P.list[(size_t)idx * RT_RECORD_WORDS + 15] & 0xFFFFu);   /* instance the ray was parked for */
-                    pm.phase = rt::PH_SCAN;
-                    if (STATS) cn.root_tests--;          /* counted when the ray was parked */
+                    if (!(P.list[(size_t)idx * RT_RECORD_WORDS] & 0x80u)) {   /* the query still has a tree to walk */
+                        pm.tv.inst = (int)(P.list[(size_t)idx * RT_RECORD_WORDS + 15] & 0xFFFFu);   /* instance the ray was parked for */
+                        pm.phase = rt::PH_SCAN;
+                        if (STATS) cn.root_tests--;      /* counted when the ray was parked */
+                    }
                 }
                 in_cur += (uint32_t)__popcll(need);
                 if (in_cur > in_end) in_cur = in_end;
@@ -813,7 +872,7 @@ rt_find_hit_kernel(const HitParams P)
 /* ---- closest-hit probes through the render kernels' own machinery: the ray's scene primitives
  * and root-box test as the shade kernel does them, a parked record for rt_tree_kernel when the
  * ray enters an instance, then the surface attributes.  Word 0 of the record: bit 0 = parked,
- * bit 7 = entered flag of the sphere tests; the tree kernel leaves it alone. */
+ * bit 6 = entered flag of the sphere tests; the tree kernel leaves it alone. */
 struct HitPackParams {
     rt_dev_scene S;
     const float *rays; uint32_t *list; uint64_t *stats;
@@ -831,7 +890,7 @@ rt_hit_pack_kernel(const HitPackParams P)
         int park = -1;
         if (!rt::query_begin<true>(P.S, o, d, P.max_distance, false, h, cn)) park = rt::query_probe<true>(P.S, o, d, h, 0, cn);
         uint4 *q = reinterpret_cast<uint4 *>(P.list + (size_t)i * RT_RECORD_WORDS);
-        const uint32_t flags = (park >= 0 ? 1u : 0u) | ((uint32_t)rt::RAY_SEGMENT << 3) | (h.entered ? 0x80u : 0u);
+        const uint32_t flags = (park >= 0 ? 1u : 0u) | ((uint32_t)rt::RAY_SEGMENT << 3) | (h.entered ? 0x40u : 0u);
         q[0] = make_uint4(flags, 0u, __float_as_uint(o.x), __float_as_uint(o.y));
         q[1] = make_uint4(__float_as_uint(o.z), __float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z));
         q[2] = make_uint4(__float_as_uint(h.t), (uint32_t)h.type, h.id, h.inst);
@@ -853,7 +912,7 @@ rt_hit_unpack_kernel(const HitPackParams P, uint8_t *results)
         rt::Hit h;
         h.t = __uint_as_float(c.x); h.type = (int)c.y; h.id = c.z; h.inst = c.w;
         h.beta = __uint_as_float(e.x); h.gamma = __uint_as_float(e.y); h.material = (int)e.z;
-        h.entered = (a.x & 0x80u) != 0u;
+        h.entered = (a.x & 0x40u) != 0u;
         rt::Surface sf;
         rt::surface_of<true>(P.S, o, d, h, sf, cn);
         write_ray_result(results + 72 * (size_t)i, h, sf);
@@ -1268,6 +1327,12 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     const bool trace_rounds = getenv("RT_GPU_TRACE_ROUNDS") != nullptr;
     uint32_t finish_below = 262144;                     /* parked records at or below which one launch finishes the paths */
     if (const char *e = getenv("RT_GPU_FINISH_BELOW")) finish_below = (uint32_t)atoll(e);
+    /* a wave that has no input left and fewer paths than this hands them to the next round; needs the
+     * finishing launch to end the frame (without it the rounds run to the last path themselves) */
+    P.tail_lanes = 0;
+    if (const char *e = getenv("RT_GPU_TAIL_LANES")) P.tail_lanes = (uint32_t)atoll(e);
+    if (P.tail_lanes > 64) P.tail_lanes = 64;
+    if (finish_below == 0) P.tail_lanes = 0;
     auto trace_t = std::chrono::steady_clock::now();
     uint64_t trace_w[RT_STAT_WORDS] = {0};
     if (trace_rounds && detailed) (void)hipMemcpy(trace_w, s->d_stats, sizeof(trace_w), hipMemcpyDeviceToHost);

@@ -701,7 +701,8 @@ enum : int { PH_SHADE = 0, PH_SCAN = 1, PH_TREE = 2, PH_DEAD = 3, PH_PARK = 4 };
 
 /* A path in transit between the shade kernel and the tree kernel: 48 words.
  * Words 0..15 (one 64-byte line) are all the tree kernel reads and writes:
- *   0 flags: valid | ev<<1 | ray<<3 | inside<<5 | fresh<<6 | seg<<8      1 x | y<<16
+ *   0 flags: valid | ev<<1 | ray<<3 | inside<<5 | fresh<<6 | ready<<7 | seg<<8      1 x | y<<16
+ *     (ready: the query is complete, the record only waits to be carried on: no tree to walk)
  *   2..4 origin   5..7 direction   8 t  9 type  10 id  11 inst  12 beta  13 gamma  14 material
  *   15 instance to (re)start the walk at | light index<<16
  * then 16..18 throughput, 19..21 radiance, 22..24 normal, 25..27 albedo, 28..30 direct,
@@ -939,11 +940,11 @@ struct PathMachine {
     /* ---- hand-over between kernels (counter generator only) ------------------- */
     int park_inst;                /* PH_PARK: instance whose tree the ray has to walk first */
 
-    __device__ __forceinline__ void store_record(uint32_t *rec, uint32_t sample_index) const
+    __device__ __forceinline__ void store_record(uint32_t *rec, uint32_t sample_index, bool ready = false) const
     {
         uint4 *q = reinterpret_cast<uint4 *>(rec);
         const uint32_t flags = 1u | ((uint32_t)ev << 1) | ((uint32_t)ray << 3) | ((uint32_t)inside_glass << 5) |
-                               ((uint32_t)rng.fresh << 6) | ((uint32_t)seg << 8);
+                               ((uint32_t)rng.fresh << 6) | ((uint32_t)ready << 7) | ((uint32_t)seg << 8);
         q[0] = make_uint4(flags, x | (y << 16), __float_as_uint(o.x), __float_as_uint(o.y));
         q[1] = make_uint4(__float_as_uint(o.z), __float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z));
         q[2] = make_uint4(__float_as_uint(h.t), (uint32_t)h.type, h.id, h.inst);
