@@ -120,7 +120,11 @@ struct ShadeParams {
     float    half_w, half_h;
 };
 
-#define RT_STAGE_WORDS (64u * 40u + 64u)   /* LDS words of a resumed-path wave: 64 record slots of 10 quads + 64 slot numbers */
+#ifndef RT_SLOTS
+#define RT_SLOTS 56u                  /* LDS record slots of a resumed-path wave: with 56 (not 64) four workgroups fit the LDS of a CU */
+#endif
+#define RT_SLOT_MASK (RT_SLOTS >= 64u ? ~0ull : (1ull << (RT_SLOTS & 63u)) - 1ull)
+#define RT_STAGE_WORDS (RT_SLOTS * 40u + 64u)   /* LDS words of a resumed-path wave: the record slots of 10 quads + 64 slot numbers */
 #define RT_STAGE_LDS ((size_t)(RT_BLOCK / 64) * RT_STAGE_WORDS * 4u)
 #ifndef RT_STAGE_REFILL
 #define RT_STAGE_REFILL 16            /* empty record slots that make a resumed-path wave fetch more of the list */
@@ -184,16 +188,16 @@ rt_shade_kernel(const ShadeParams P)
     bool cursor_done = false;
     bool input_done = false;
     extern __shared__ uint32_t lds[];
-    /* Resumed paths: records come from the list through 64 LDS slots per wave (slot j is filled by
+    /* Resumed paths: records come from the list through RT_SLOTS LDS slots per wave (slot j is filled by
      * lane j with global_load_lds: no registers, nothing to wait for at issue; quad q of slot j at
-     * word (q * 64 + j) * 4).  A record's kind of next step is known before a lane takes it, so a
+     * word (q * RT_SLOTS + j) * 4).  A record's kind of next step is known before a lane takes it, so a
      * free lane takes a record of the kind the wave is about to run: the lanes stay together. */
     uint32_t *stage = lds + (threadIdx.x >> 6) * RT_STAGE_WORDS;
-    uint32_t *pick = stage + 64u * 40u;                 /* slot numbers handed to the free lanes */
+    uint32_t *pick = stage + RT_SLOTS * 40u;                 /* slot numbers handed to the free lanes */
     unsigned long long ready = 0, flight = 0;           /* slots holding a record / being filled */
     int slot_kind = 0;                                  /* kind of the record in slot `lane` */
     auto stage_issue = [&]() {                           /* fill the empty slots from the list */
-        const unsigned long long empty = ~(ready | flight);
+        const unsigned long long empty = ~(ready | flight) & RT_SLOT_MASK;
         if (in_cur >= in_end && !cursor_done) {
             uint32_t v = 0;
             if (lane == 0) v = atomicAdd(&P.q->in_next, RT_IN_BATCH);
@@ -209,7 +213,7 @@ rt_shade_kernel(const ShadeParams P)
             const uint32_t *src = P.in_list + (size_t)(in_cur + rank) * RT_RECORD_WORDS;
 #pragma unroll
             for (uint32_t qd = 0; qd < 10u; qd++)
-                __builtin_amdgcn_global_load_lds(src + 4u * qd, stage + 4u * 64u * qd, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(src + 4u * qd, stage + 4u * RT_SLOTS * qd, 16, 0, 0);
         }
         flight |= __ballot(mine);
         in_cur += n;
@@ -219,7 +223,7 @@ rt_shade_kernel(const ShadeParams P)
         __builtin_amdgcn_s_waitcnt(0x0F70);              /* vmcnt(0) */
         bool ok = false;
         if ((flight >> lane) & 1ull) {
-            const uint32_t f = stage[lane * 4u], w = stage[(3u * 64u + lane) * 4u + 3u];
+            const uint32_t f = stage[lane * 4u], w = stage[(3u * RT_SLOTS + lane) * 4u + 3u];
             const int ev = (int)((f >> 1) & 3u), ray = (int)((f >> 3) & 3u), li = (int)(w >> 16);
             slot_kind = ray == rt::RAY_SEGMENT ? 1 : (ev == rt::EV_NEE ? (li + 1 < P.S.light_count ? 2 : 3) : 0);
             slot_kind = RT_KIND_CLASS(false, slot_kind);
@@ -393,7 +397,7 @@ rt_shade_kernel(const ShadeParams P)
                     const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
                     if (!has && rank < take) {
                         const uint32_t j = pick[rank];
-                        has = pm.load_record(reinterpret_cast<const uint4 *>(stage) + j, 64u, sample_index);
+                        has = pm.load_record(reinterpret_cast<const uint4 *>(stage) + j, RT_SLOTS, sample_index);
                     }
                 }
             }
@@ -413,7 +417,7 @@ rt_shade_kernel(const ShadeParams P)
 
         if (!FRESH) {                                    /* what was asked for during the last step has long arrived */
             stage_land();
-            if (__popcll(~(ready | flight)) >= RT_STAGE_REFILL && !(cursor_done && in_cur >= in_end)) stage_issue();
+            if (__popcll(~(ready | flight)) - (64 - (int)RT_SLOTS) >= RT_STAGE_REFILL && !(cursor_done && in_cur >= in_end)) stage_issue();
         }
 
         /* ---- 3. park the lanes whose ray has to walk a tree ------------------------- */
@@ -1329,7 +1333,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     if (const char *e = getenv("RT_GPU_FINISH_BELOW")) finish_below = (uint32_t)atoll(e);
     /* a wave that has no input left and fewer paths than this hands them to the next round; needs the
      * finishing launch to end the frame (without it the rounds run to the last path themselves) */
-    P.tail_lanes = 0;
+    P.tail_lanes = 32;
     if (const char *e = getenv("RT_GPU_TAIL_LANES")) P.tail_lanes = (uint32_t)atoll(e);
     if (P.tail_lanes > 64) P.tail_lanes = 64;
     if (finish_below == 0) P.tail_lanes = 0;

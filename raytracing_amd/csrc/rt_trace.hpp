@@ -949,7 +949,7 @@ struct PathMachine {
         q[1] = make_uint4(__float_as_uint(o.z), __float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z));
         q[2] = make_uint4(__float_as_uint(h.t), (uint32_t)h.type, h.id, h.inst);
         q[3] = make_uint4(__float_as_uint(h.beta), __float_as_uint(h.gamma), (uint32_t)h.material,
-                          (uint32_t)park_inst | ((uint32_t)li << 16));
+                          ((uint32_t)park_inst & 0xFFFFu) | ((uint32_t)li << 16));   /* park_inst is -1 or unset when the query is complete */
         q[4] = make_uint4(__float_as_uint(throughput.x), __float_as_uint(throughput.y), __float_as_uint(throughput.z),
                           __float_as_uint(radiance.x));
         q[5] = make_uint4(__float_as_uint(radiance.y), __float_as_uint(radiance.z), __float_as_uint(n.x),

@@ -301,15 +301,18 @@ def test_sample_batches_continue_bit_exactly(gpu_scenes):
 def test_memory_budgets_and_round_policies_do_not_change_the_picture(gpu_scenes, monkeypatch):
     """How a frame is cut into launches is an implementation matter: a small sample scratch (several
     sample batches per call), a parked-list budget that forces batches, rounds to the very end
-    (no finishing launch) and a finishing launch right after the first one must all give the
-    oracle's bits; a parked-list budget too small for one sample per pixel is an error."""
+    (no finishing launch), a finishing launch right after the first one, and waves that hand their
+    last paths to the next round early, late or never must all give the oracle's bits; a parked-list
+    budget too small for one sample per pixel is an error."""
     sh, gs = gpu_scenes("three_dogs")
     W = H = 96
     want = oracle_counter(sh, W, H, (0, 0, W, H), 12, 5)
     cases = [{}, {"RT_GPU_SCRATCH_MB": "1"}, {"RT_GPU_PARKED_MB": "421"}, {"RT_GPU_FINISH_BELOW": "0"},
-             {"RT_GPU_FINISH_BELOW": "4000000000"}, {"RT_GPU_SCRATCH_MB": "1", "RT_GPU_FINISH_BELOW": "0"}]
+             {"RT_GPU_FINISH_BELOW": "4000000000"}, {"RT_GPU_SCRATCH_MB": "1", "RT_GPU_FINISH_BELOW": "0"},
+             {"RT_GPU_TAIL_LANES": "0"}, {"RT_GPU_TAIL_LANES": "64", "RT_GPU_FINISH_BELOW": "100"},
+             {"RT_GPU_TAIL_LANES": "8", "RT_GPU_FINISH_BELOW": "1"}]
     for env in cases:
-        for k in ("RT_GPU_SCRATCH_MB", "RT_GPU_PARKED_MB", "RT_GPU_FINISH_BELOW"):
+        for k in ("RT_GPU_SCRATCH_MB", "RT_GPU_PARKED_MB", "RT_GPU_FINISH_BELOW", "RT_GPU_TAIL_LANES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
