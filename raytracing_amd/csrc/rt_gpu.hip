@@ -78,7 +78,8 @@ __device__ __forceinline__ void flush_counters(const rt::Counters &cn, uint64_t 
  *
  * Round 0 shades fresh (pixel, sample) items; round r > 0 resumes the paths
  * parked in round r-1 after the tree kernel has answered their queries.  The
- * loop ends when a shade launch parks nothing.  A path executes exactly the
+ * loop ends when a shade launch parks nothing, or with rt_finish_kernel once
+ * few paths are left.  A path executes exactly the
  * operations of the host's nested loops in the same order whatever lane or
  * launch runs them, so results do not change.
  * ------------------------------------------------------------------------ */

@@ -71,3 +71,20 @@ def test_product_does_not_reach_into_the_oracle():
                     if re.search(r"oracle/|rt_oracle|librt_oracle|_ref/|libref_", text):
                         bad.append(os.path.join(d, f))
     assert bad == []
+
+
+def test_work_model_constants_are_the_record_sizes():
+    """include/rt_work_model.h prices the counted work with the sizes of the reference's records
+    (src/math.h, src/main.h): a constant that drifts from the layout would skew every roofline."""
+    text = open(os.path.join(ROOT, "include", "rt_work_model.h")).read()
+    m = {k: int(v) for k, v in re.findall(r"#define\s+(RT_(?:BYTES|FLOPS)_\w+)\s+(\d+)", text)}
+    size = {t.__name__: n for t, n in T.LAYOUT_SIZES}
+    assert m["RT_BYTES_LIGHT_TEST"] == size["Light"] and m["RT_BYTES_SPHERE_TEST"] == size["Sphere"]
+    assert m["RT_BYTES_PLANE_TEST"] == size["Plane"]
+    assert m["RT_BYTES_ROOT_TEST"] == size["Transform"] + 24
+    assert m["RT_BYTES_INTERIOR_POP"] == 2 * size["MeshNode"]
+    assert m["RT_BYTES_TRI_TEST"] == size["Triangle"] + 3 * 12
+    assert m["RT_BYTES_TRI_HIT"] == 3 * 12 + 3 * 8 and m["RT_BYTES_TEX_LOOKUP"] == 12 and m["RT_BYTES_PIXEL"] == 12
+    assert len([k for k in m if k.startswith("RT_FLOPS_")]) == 8
+    import bench
+    assert bench.work_model() == m
