@@ -298,6 +298,23 @@ def test_sample_batches_continue_bit_exactly(gpu_scenes):
     assert L.same_bits(got, oracle_counter(sh, W, H, (0, 0, W, H), 3, seed, sample_offset=2)).all()
 
 
+def test_progressive_frame_with_a_checkpoint_in_the_middle(gpu_scenes, tmp_path):
+    """3 samples, checkpoint to a file, a new frame object from the file, 4 more samples: the frame
+    is the oracle's 7-sample frame bit for bit, and the intermediate frame its 3-sample frame."""
+    from raytracing_amd import progressive
+    sh, gs = gpu_scenes("sphere_room")
+    W, H, seed = 40, 32, (5 << 32) | 77
+    f = progressive.ProgressiveFrame(gs, W, H, seed)
+    f.add_samples(3)
+    assert L.same_bits(f.frame().cpu().numpy(), oracle_counter(sh, W, H, (0, 0, W, H), 3, seed)).all()
+    path = str(tmp_path / "frame.npz")
+    f.save(path)
+    g = progressive.ProgressiveFrame.load(path, gs)
+    assert (g.samples, g.seed, g.width, g.height) == (3, seed, W, H)
+    g.add_samples(4)
+    assert L.same_bits(g.frame().cpu().numpy(), oracle_counter(sh, W, H, (0, 0, W, H), 7, seed)).all()
+
+
 def test_memory_budgets_and_round_policies_do_not_change_the_picture(gpu_scenes, monkeypatch):
     """How a frame is cut into launches is an implementation matter: a small sample scratch (several
     sample batches per call), a parked-list budget that forces batches, rounds to the very end

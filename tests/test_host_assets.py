@@ -3,6 +3,7 @@ import ctypes as C
 import hashlib
 
 import numpy as np
+import pytest
 
 import _libs as L
 from raytracing_amd import host, scenes, scene_types as T
@@ -114,3 +115,14 @@ def test_portable_display_transfer_equals_libm_transfer():
     out = np.zeros(1, np.uint8)
     L.oracle().orc_quantize_portable(one.ctypes.data, 1, out.ctypes.data)
     assert out[0] == 32                                                                     # the correctly rounded power gives 32
+
+
+def test_progressive_checkpoint_header_checks():
+    """A checkpoint must describe its own array; the check runs on the host."""
+    from raytracing_amd import progressive
+    sums = np.zeros((4, 6, 3), np.float32)
+    progressive.check_checkpoint(sums, [6, 4, 2, 1, 0, 0])
+    for bad_sums, bad_meta in [(sums, [4, 6, 2, 1, 0, 0]), (sums.astype(np.float64), [6, 4, 2, 1, 0, 0]),
+                               (sums, [6, 4, 2]), (np.full((4, 6, 3), np.nan, np.float32), [6, 4, 2, 1, 0, 0])]:
+        with pytest.raises(ValueError):
+            progressive.check_checkpoint(bad_sums, bad_meta)
