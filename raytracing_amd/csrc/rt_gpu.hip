@@ -1142,6 +1142,11 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
             int per_cu_resume = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_resume, rt_shade_kernel<false, false, true>, RT_BLOCK, RT_STAGE_LDS) != hipSuccess || per_cu_resume < 1) per_cu_resume = 1;
             s->resume_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_resume);
+            if (const char *e = getenv("RT_GPU_FRESH_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu_shade) per_cu_shade = v; }
+            if (const char *e = getenv("RT_GPU_RESUME_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu_resume) per_cu_resume = v; }
+            if (const char *e = getenv("RT_GPU_TREE_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu_tree) per_cu_tree = v; }
+            s->resume_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_resume);
+            s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
             s->shade_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_shade);
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
         }
