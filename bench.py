@@ -13,7 +13,7 @@ The frame is the same whatever N is (the generator is keyed by pixel and sample)
 strong scaling of a fixed frame.
 
 Frames are independent, and the end of a frame is latency-bound (a few long paths, a few
-thousand rays per launch), so --frames-in-flight of them (default 3) are rendered concurrently,
+thousand rays per launch), so --frames-in-flight of them (default 3 or 4; 4 or 6 with N > 1) are rendered concurrently,
 each on its own stream with its own device work lists: the tail of frame i overlaps the
 machine-filling first launch of frame i+1 and, with N > 1, the all-gather of frame i overlaps
 rendering.  Every timed frame is complete (rendered, gathered, assembled) inside the timed
@@ -137,10 +137,14 @@ def main():
     ap.add_argument("--split", choices=("bands", "samples"), default="bands",
                     help="how N devices share a frame: 8-row bands (bit-identical to one device) or sample ranges of "
                          "every pixel, summed in rank order (equal up to float summation order; for small frames)")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
-                    help="frames rendered concurrently (each with its own stream and device work lists)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames rendered concurrently, each with its own stream and device work lists "
+                         "(0 = 3 or 4 on one GPU, 4 or 6 when the frame is shared by several, by the number of steps)")
     args = ap.parse_args()
 
+    # every frame in flight has its own stream; HIP maps streams onto 4 hardware queues unless told otherwise,
+    # and frames that share a queue run one after the other
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     from raytracing_amd import gpu, multi_gpu, scenes
 
@@ -202,7 +206,13 @@ def main():
     W, H, spp = args.width, args.height, args.spp
     band = multi_gpu.BAND_ROWS
     sh = scenes.CONFIGS[args.scene]()
-    in_flight = max(1, args.frames_in_flight)
+    # more frames in flight overlap more, but the timed region starts and ends with a partly filled pipeline
+    if args.frames_in_flight > 0:
+        in_flight = args.frames_in_flight
+    elif world == 1:
+        in_flight = 4 if args.steps >= 16 else 3
+    else:
+        in_flight = 6 if args.steps >= 12 else 4
     by_samples = world > 1 and args.split == "samples"
     my_spp = spp
 

@@ -1335,7 +1335,12 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     const uint32_t resolve_grid = (uint32_t)((units * 64 + RT_BLOCK - 1) / RT_BLOCK);
 
     const bool trace_rounds = getenv("RT_GPU_TRACE_ROUNDS") != nullptr;
-    uint32_t finish_below = 262144;                     /* parked records at or below which one launch finishes the paths */
+    /* parked records at or below which one launch finishes the paths: 1/128 of the launch's paths, within
+     * [65536, 262144] (the finishing launch runs few lanes per wave, so a small launch must not leave it much) */
+    uint64_t finish_paths = per_launch * items_per_sample / 128;
+    if (finish_paths < 65536) finish_paths = 65536;
+    if (finish_paths > 262144) finish_paths = 262144;
+    uint32_t finish_below = (uint32_t)finish_paths;
     if (const char *e = getenv("RT_GPU_FINISH_BELOW")) finish_below = (uint32_t)atoll(e);
     /* a wave that has no input left and fewer paths than this hands them to the next round; needs the
      * finishing launch to end the frame (without it the rounds run to the last path themselves) */
