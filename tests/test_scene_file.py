@@ -1,0 +1,70 @@
+"""Scenes written as JSON documents give the very records the hand-built scenes have (no GPU needed)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _libs as L
+from raytracing_amd import gpu, host, scene_file, scenes
+
+DOG_FILES = dict(textures={"dog_diffuse": "dog_texture_rgb8.npz"}, meshes={"dog": "dog_obj.npz"})
+
+
+def _bytes(array, count):
+    return bytes(C.string_at(C.addressof(array), C.sizeof(array._type_) * count))
+
+
+def _render(sh, W=24, H=16, spp=2, seed=5):
+    img, arr = host.new_image(W, H)
+    r = gpu.rect(0, 0, W, H)
+    L.oracle().orc_render_region_counter(sh.ptr, C.byref(img), C.byref(r), spp, 0, seed, L.MATH_PORTABLE, 64, None)
+    return arr
+
+
+@pytest.mark.parametrize("name", sorted(scenes.CONFIGS))
+def test_document_round_trip_gives_the_same_records_and_the_same_picture(name, tmp_path):
+    sh = scenes.CONFIGS[name]()
+    files = DOG_FILES if sh.scene.mesh_count else {}
+    text = json.dumps(scene_file.describe(sh, **files))
+    path = tmp_path / "scene.json"
+    path.write_text(text)
+    back = scene_file.load(str(path), base_dir=scenes.GOLDEN_DIR)
+    a, b = sh.scene, back.scene
+    assert bytes(a.camera) == bytes(b.camera)
+    for field, count in (("spheres", a.sphere_count), ("planes", a.plane_count), ("lights", a.light_count)):
+        assert getattr(b, field.rstrip("s") + "_count") == count
+        assert _bytes(getattr(sh, field), count) == _bytes(getattr(back, field), count)
+    assert a.material_count == b.material_count and a.mesh_count == b.mesh_count
+    for i in range(a.material_count):
+        ma, mb = a.materials[i], b.materials[i]
+        assert (bytes(ma.diffuse_color), ma.mirror, bytes(ma.mirror_color), ma.transparent, ma.n, ma.textured) == \
+               (bytes(mb.diffuse_color), mb.mirror, bytes(mb.mirror_color), mb.transparent, mb.n, mb.textured)
+    for i in range(a.mesh_count):
+        assert bytes(a.meshes[i].transform) == bytes(b.meshes[i].transform)
+        assert a.meshes[i].material_id == b.meshes[i].material_id
+        assert a.meshes[i].mesh.contents.face_count == b.meshes[i].mesh.contents.face_count
+    assert L.same_bits(_render(sh), _render(back)).all()
+
+
+def test_fov_in_degrees_is_the_reference_expression():
+    doc = {"camera": {"position": [0, 10, 85], "look_at": [0, 0, 0], "up": [0, 1, 0], "fov_degrees": 60}}
+    sh = scene_file.load(doc)
+    assert bytes(sh.scene.camera) == bytes(scenes.room_camera())
+
+
+@pytest.mark.parametrize("doc", [
+    {},
+    {"camera": {"position": [0, 0, 1], "look_at": [0, 0, 0], "up": [0, 1, 0]}},
+    {"camera": {"position": [0, 0], "look_at": [0, 0, 0], "up": [0, 1, 0], "fov": 1.0}},
+    {"camera": {"position": [0, 0, 1], "look_at": [0, 0, 0], "up": [0, 1, 0], "fov": 1.0},
+     "materials": [{"diffuse": [1, 1, 1]}], "spheres": [{"center": [0, 0, 0], "radius": 1, "material": 1}]},
+    {"camera": {"position": [0, 0, 1], "look_at": [0, 0, 0], "up": [0, 1, 0], "fov": 1.0},
+     "materials": [{"diffuse": [1, 1, 1], "mirror": [1, 1, 1]}]},
+    {"camera": {"position": [0, 0, 1], "look_at": [0, 0, 0], "up": [0, 1, 0], "fov": 1.0},
+     "materials": [{"diffuse": [1, 1, 1]}], "instances": [{"mesh": "nope", "position": [0, 0, 0], "material": 0}]},
+])
+def test_malformed_documents_are_refused(doc):
+    with pytest.raises(scene_file.SceneFileError):
+        scene_file.load(doc)
