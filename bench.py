@@ -134,6 +134,10 @@ def main():
     ap.add_argument("--rehearse-ranks", type=int, default=0,
                     help="single process, single GPU: act as rank 0 of this many ranks and render the other ranks' "
                          "shares in place of the all-gather (a check of the multi-GPU path, not a measurement)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend: nccl (= RCCL over xGMI, one GPU per rank); gloo gathers through host "
+                         "memory and lets several ranks share a GPU (a functional check of the multi-process path on a "
+                         "machine with fewer GPUs than ranks, not a measurement)")
     ap.add_argument("--split", choices=("bands", "samples"), default="bands",
                     help="how N devices share a frame: 8-row bands (bit-identical to one device) or sample ranges of "
                          "every pixel, summed in rank order (equal up to float summation order; for small frames)")
@@ -156,11 +160,16 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())      # ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     elif args.rehearse_ranks > 1:
         # One process plays rank 0 of N: the other ranks' shares are rendered here as well, inside
         # the stand-in for the all-gather.  Exercises the band split, the packed buffers and the
@@ -263,7 +272,13 @@ def main():
             with torch.cuda.stream(ln.stream):
                 if args.rehearse_ranks > 1:
                     dist.seed = ln.seed
-                dist.all_gather_into_tensor(ln.gathered, ln.mine)
+                if args.backend == "gloo" and args.rehearse_ranks <= 1:   # through host memory
+                    ln.stream.synchronize()
+                    host_all = torch.empty(ln.gathered.shape, dtype=torch.float32)
+                    dist.all_gather_into_tensor(host_all, ln.mine.cpu())
+                    ln.gathered.copy_(host_all)
+                else:
+                    dist.all_gather_into_tensor(ln.gathered, ln.mine)
                 if by_samples:
                     frame = multi_gpu.combine_partial_sums(ln.gathered, world, spp)
                 else:
@@ -314,9 +329,10 @@ def main():
     resume_ms = (st["shade_ms"] - st["fresh_ms"]) / frames
     resume_launches = max(0.0, st["rounds"] / frames - 1)           # each resume launch follows one tree launch
     if world > 1:
-        t = torch.tensor([elapsed, fresh_ms, resume_ms, tree_ms, finish_ms], dtype=torch.float64, device="cuda")
+        where = "cuda" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed, fresh_ms, resume_ms, tree_ms, finish_ms], dtype=torch.float64, device=where)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        r = torch.tensor([rays], dtype=torch.float64, device="cuda")
+        r = torch.tensor([rays], dtype=torch.float64, device=where)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         elapsed, fresh_ms, resume_ms, tree_ms, finish_ms = (float(x) for x in t)
         rays = float(r[0])
