@@ -88,3 +88,38 @@ def test_work_model_constants_are_the_record_sizes():
     assert len([k for k in m if k.startswith("RT_FLOPS_")]) == 8
     import bench
     assert bench.work_model() == m
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/main.c"), reason="reference sources not present")
+def test_documented_binding_compiles_inside_the_reference_program(tmp_path):
+    """The block a maintainer would put into src/main.c: rt_gpu.h with the host's own records as its
+    types, the render block of src/main.c:1056-1088 replaced by library calls.  Compiled (not run)
+    against the reference's own source with its build.sh flags."""
+    src = tmp_path / "with_gpu.c"
+    src.write_text('''
+#define main ref_program_main
+#include "/root/reference/src/main.c"
+#undef main
+#define RT_SCENE_TYPES_FROM_HOST
+#include "rt_gpu.h"
+int render_with_gpu(Scene *scene, Image3f *images, int count)
+{
+    rt_gpu_scene *gpu_scene = NULL;
+    if (rt_gpu_scene_create(scene, &gpu_scene) != 0) { fprintf(stderr, "%s\\n", rt_gpu_last_error()); return -1; }
+    for (int i = 0; i < count; i++) {
+        Rect2i whole = { .point = {0, 0}, .size = {IMAGE_SIZE, IMAGE_SIZE} };
+        if (rt_gpu_render_region(gpu_scene, images + i, whole, RAY_PER_PIXEL, i, NULL) != 0) return -2;
+    }
+    Job job; memset(&job, 0, sizeof(job));
+    Ray ray; Ray_Result hit; memset(&ray, 0, sizeof(ray));
+    if (rt_gpu_render_jobs(gpu_scene, &job, 1, NULL) != 0) return -3;
+    if (rt_gpu_find_ray_hit(gpu_scene, &ray, 1, 1e30f, &hit) != 0) return -4;
+    rt_gpu_scene_destroy(gpu_scene);
+    return 0;
+}
+''')
+    obj = tmp_path / "with_gpu.o"
+    r = subprocess.run(["gcc", "-c", str(src), "-o", str(obj), "-O1", "-maes", "-mfma", "-D_REENTRANT", "-DUSE_THREADS=1",
+                        "-I", os.path.join(ROOT, "include"), "-w"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    assert obj.stat().st_size > 0
