@@ -324,7 +324,7 @@ def main():
     run_frames([0, 1, 2], depth=1)
     fence()
     st = g.stats()
-    frames = max(1, st["launches"])
+    frames = 3                                       # (a frame is several launches when its samples come in batches)
     fresh_ms, tree_ms, finish_ms = st["fresh_ms"] / frames, st["tree_ms"] / frames, st["finish_ms"] / frames
     resume_ms = (st["shade_ms"] - st["fresh_ms"]) / frames
     resume_launches = max(0.0, st["rounds"] / frames - 1)           # each resume launch follows one tree launch
@@ -378,8 +378,8 @@ def main():
             "data": "dog model + texture from the parsed-asset fixtures in tests/golden, room scene from the "
                     "reference's main(); random numbers from the counter generator, seed = step index",
             "config": {
-                "workload": f"{args.scene} {W}x{H} {spp} spp, {args.max_segments}-segment paths "
-                            "(config 4: dog.obj textured, BVH, indirect lighting)",
+                "workload": f"{args.scene} {W}x{H} {spp} spp, {args.max_segments}-segment paths" +
+                            (" (config 4: dog.obj textured, BVH, indirect lighting)" if args.scene == "dog_room" else ""),
                 "rays_per_step": round(rays / args.steps),
                 "rays_per_sample": round(rays / args.steps / (W * H * spp), 3),
                 "ms_per_frame": round(1e3 * elapsed / args.steps, 3),
