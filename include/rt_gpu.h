@@ -67,6 +67,13 @@ typedef struct rt_gpu_options {
     uint32_t band_rows;      /* split over devices: rows per band (multiple of 8); 0 = no split */
     uint32_t band_rank;      /* this device renders bands rank, rank + count, ... of the region */
     uint32_t band_count;
+    uint32_t frames;         /* device render only: frames rendered by this call; 0 or 1 = one.  Frame k is made of
+                              * samples sample_offset + k*spp ... + spp - 1 of every pixel and is stored frame_stride
+                              * floats after frame k-1: the same pictures as `frames` calls with those sample offsets,
+                              * from launches `frames` times as large (small regions fill the GPU better that way) */
+    uint32_t reserved;
+    uint64_t frame_stride;   /* floats between the first pixels of consecutive frames; 0 = the size of one frame's
+                              * output (width*height*3, or this rank's packed bands) */
 } rt_gpu_options;
 
 /* Work counters of the calls since the last rt_gpu_reset_stats.  A "ray" is

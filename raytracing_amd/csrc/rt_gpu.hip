@@ -1275,6 +1275,13 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     const uint32_t flags = o ? o->flags : 0;
     const bool detailed = (flags & RT_GPU_FLAG_DETAILED_STATS) != 0;
     const bool accumulate = (flags & RT_GPU_FLAG_ACCUMULATE) != 0;
+    const uint32_t frames = (o && o->frames > 1) ? o->frames : 1;
+    if ((uint64_t)spp * frames + (o ? o->sample_offset : 0) > 0xFFFFFFFFull) return fail(RT_GPU_ERR_ARGUMENT, "sample indices exceed 32 bits");
+    const uint64_t frame_floats = (flags & RT_GPU_FLAG_COMPACT_BANDS) ? (uint64_t)own_rows * region.size.x * 3
+                                                                      : (uint64_t)width * height * 3;
+    const uint64_t frame_stride = (o && o->frame_stride) ? o->frame_stride : frame_floats;
+    if (frames > 1 && frame_stride < frame_floats) return fail(RT_GPU_ERR_ARGUMENT, "frame_stride is smaller than a frame");
+    const uint64_t total_spp = (uint64_t)spp * frames;
 
     ShadeParams P;
     memset(&P, 0, sizeof(P));
@@ -1319,9 +1326,23 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     if (list_records < items_per_sample + chunk_slack)
         return fail(RT_GPU_ERR_MEMORY, "RT_GPU_PARKED_MB is too small for one sample per pixel of this region");
     if (per_launch > (list_records - chunk_slack) / items_per_sample) per_launch = (list_records - chunk_slack) / items_per_sample;
-    if (per_launch > spp) per_launch = spp;
+    if (per_launch > total_spp) per_launch = total_spp;
     if (per_launch * items_per_sample > 0xFFFFFF00ull / 3) per_launch = (0xFFFFFF00ull / 3) / items_per_sample;
     if (per_launch < 1) return fail(RT_GPU_ERR_ARGUMENT, "region too large for one launch");
+    if (frames > 1) {
+        if (per_launch < spp) {
+            /* not even one frame fits a launch: the frames one after the other, each in its sample batches */
+            rt_gpu_options one = *o;
+            one.frames = 1; one.frame_stride = 0;
+            for (uint32_t k = 0; k < frames; k++) {
+                one.sample_offset = o->sample_offset + k * spp;
+                rc = rt_gpu_render_region_device(s, device_pixels + (size_t)k * frame_stride, width, height, region, spp, seed, &one, hip_stream);
+                if (rc) return rc;
+            }
+            return RT_GPU_OK;
+        }
+        per_launch -= per_launch % spp;                  /* whole frames per launch */
+    }
     uint64_t capacity = per_launch * items_per_sample + chunk_slack;
     capacity = (capacity + RT_CHUNK - 1) / RT_CHUNK * RT_CHUNK;
     if (capacity > 0xFFFFFF00ull) return fail(RT_GPU_ERR_ARGUMENT, "region too large for one launch");
@@ -1351,9 +1372,10 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     auto trace_t = std::chrono::steady_clock::now();
     uint64_t trace_w[RT_STAT_WORDS] = {0};
     if (trace_rounds && detailed) (void)hipMemcpy(trace_w, s->d_stats, sizeof(trace_w), hipMemcpyDeviceToHost);
-    for (uint32_t first = 0; first < spp; first += (uint32_t)per_launch) {
+    for (uint64_t first64 = 0; first64 < total_spp; first64 += per_launch) {
+        const uint32_t first = (uint32_t)first64;
         P.first_sample = first;
-        P.launch_spp = (uint32_t)(spp - first < per_launch ? spp - first : per_launch);
+        P.launch_spp = (uint32_t)(total_spp - first64 < per_launch ? total_spp - first64 : per_launch);
         uint32_t *list_in = s->d_parked[0], *list_out = s->d_parked[1];
         uint32_t in_slots = 0, in_records = 0;
         for (uint32_t round = 0;; round++) {
@@ -1436,15 +1458,29 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
             uint32_t *tmp = list_in; list_in = list_out; list_out = tmp;
             in_slots = parked; in_records = qc.parked;
         }
-        R.launch_spp = P.launch_spp;
-        R.start_from_pixels = (accumulate || first > 0) ? 1 : 0;
-        R.finish = (!accumulate && first + P.launch_spp >= spp) ? 1 : 0;
-        hipLaunchKernelGGL(rt_resolve_kernel, dim3(resolve_grid), dim3(RT_BLOCK), 0, stream, R);
-        RT_HIP(hipGetLastError());
+        if (frames == 1) {
+            R.launch_spp = P.launch_spp;
+            R.start_from_pixels = (accumulate || first > 0) ? 1 : 0;
+            R.finish = (!accumulate && first + P.launch_spp >= spp) ? 1 : 0;
+            hipLaunchKernelGGL(rt_resolve_kernel, dim3(resolve_grid), dim3(RT_BLOCK), 0, stream, R);
+            RT_HIP(hipGetLastError());
+        } else {
+            /* the launch holds whole frames: frame j of it owns samples j*spp ... of the scratch */
+            for (uint32_t j = 0; j < P.launch_spp / spp; j++) {
+                ResolveParams F = R;
+                F.samples = P.samples + 3 * (size_t)j * spp * items_per_sample;
+                F.pixels = device_pixels + (size_t)(first / spp + j) * frame_stride;
+                F.launch_spp = spp;
+                F.start_from_pixels = accumulate ? 1 : 0;
+                F.finish = accumulate ? 0 : 1;
+                hipLaunchKernelGGL(rt_resolve_kernel, dim3(resolve_grid), dim3(RT_BLOCK), 0, stream, F);
+                RT_HIP(hipGetLastError());
+            }
+        }
         s->launches++;
     }
     if (s->timers.size() + s->tree_timers.size() > 4096) settle_timers(s);
-    s->samples += (uint64_t)spp * own_rows * region.size.x;
+    s->samples += total_spp * own_rows * region.size.x;
     return RT_GPU_OK;
 }
 
@@ -1463,6 +1499,7 @@ int rt_gpu_render_region(rt_gpu_scene *s, rt_image3f *image, rt_rect2u region, u
 {
     if (!s || !image || !image->pixels) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_render_region: NULL argument");
     if (o && (o->flags & RT_GPU_FLAG_COMPACT_BANDS)) return fail(RT_GPU_ERR_ARGUMENT, "compact bands are a device-buffer layout");
+    if (o && o->struct_size == sizeof(rt_gpu_options) && o->frames > 1) return fail(RT_GPU_ERR_ARGUMENT, "several frames per call need the device-buffer entry point");
     const uint32_t W = image->size.x, H = image->size.y;
     if ((uint64_t)region.point.x + region.size.x > W || (uint64_t)region.point.y + region.size.y > H)
         return fail(RT_GPU_ERR_ARGUMENT, "region exceeds the image");

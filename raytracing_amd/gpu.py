@@ -29,7 +29,7 @@ EXPORTS = [
 class Options(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "struct_size", "max_segments", "sample_offset", "spp_total", "flags",
-        "band_rows", "band_rank", "band_count")]
+        "band_rows", "band_rank", "band_count", "frames", "reserved")] + [("frame_stride", C.c_uint64)]
 
     def __init__(self, **kw):
         super().__init__()

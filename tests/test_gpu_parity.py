@@ -298,6 +298,54 @@ def test_sample_batches_continue_bit_exactly(gpu_scenes):
     assert L.same_bits(got, oracle_counter(sh, W, H, (0, 0, W, H), 3, seed, sample_offset=2)).all()
 
 
+def test_several_frames_in_one_call(gpu_scenes, monkeypatch):
+    """options.frames = 3: frame k is made of samples sample_offset + k*spp ... of every pixel and lands
+    frame_stride floats after frame k-1: each equals the oracle's frame with that sample offset, in
+    the plain layout, in the packed bands of a rank, and when the sample scratch is too small for a
+    whole frame per launch (the frames then run one after the other)."""
+    import torch
+    from raytracing_amd import multi_gpu
+    sh, gs = gpu_scenes("dog_room")
+    W, H, spp, seed, frames = 48, 32, 3, 19, 3
+    want = [oracle_counter(sh, W, H, (0, 0, W, H), spp, seed, sample_offset=5 + k * spp) for k in range(frames)]
+    for env in ({}, {"RT_GPU_SCRATCH_MB": "0"}):
+        monkeypatch.delenv("RT_GPU_SCRATCH_MB", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        if env:       # 0 MB would refuse to render at all: give it room for two samples of the region
+            monkeypatch.setenv("RT_GPU_SCRATCH_MB", "1")
+            big_w, big_h = 256, 192                     # 49152 pixels x 12 B x 3 spp > 1 MB
+            want_big = [oracle_counter(sh, big_w, big_h, (0, 0, big_w, big_h), spp, seed, sample_offset=k * spp) for k in range(2)]
+            buf = torch.zeros((2, big_h, big_w, 3), dtype=torch.float32, device="cuda")
+            gs.render_region_device(buf.data_ptr(), big_w, big_h, (0, 0, big_w, big_h), spp, seed, gpu.Options(frames=2))
+            torch.cuda.synchronize()
+            for k in range(2):
+                assert L.same_bits(buf[k].cpu().numpy(), want_big[k]).all(), k
+            continue
+        pad = 7 * 3                                     # frames need not be contiguous
+        buf = torch.full((frames * (H * W * 3 + pad),), -1.0, dtype=torch.float32, device="cuda")
+        gs.render_region_device(buf.data_ptr(), W, H, (0, 0, W, H), spp, seed,
+                                gpu.Options(frames=frames, sample_offset=5, frame_stride=H * W * 3 + pad))
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy().reshape(frames, H * W * 3 + pad)
+        for k in range(frames):
+            assert L.same_bits(got[k, :H * W * 3].reshape(H, W, 3), want[k]).all(), k
+            assert (got[k, H * W * 3:] == -1.0).all()
+        world, rank = 2, 1
+        rows = multi_gpu.packed_rows(world, H)
+        mine = torch.zeros((frames, rows, W, 3), dtype=torch.float32, device="cuda")
+        gs.render_region_device(mine.data_ptr(), W, H, (0, 0, W, H), spp, seed,
+                                gpu.Options(frames=frames, sample_offset=5, band_rows=8, band_rank=rank, band_count=world,
+                                            flags=gpu.FLAG_COMPACT_BANDS))
+        torch.cuda.synchronize()
+        own = multi_gpu.rows_of_rank(rank, world, H)
+        for k in range(frames):
+            assert L.same_bits(mine[k, :len(own)].cpu().numpy(), want[k][own]).all(), k
+    img, arr = host.new_image(W, H)
+    with pytest.raises(RuntimeError, match="device-buffer"):
+        gs.render_region(img, (0, 0, W, H), spp, seed, gpu.Options(frames=2))
+
+
 def test_progressive_frame_with_a_checkpoint_in_the_middle(gpu_scenes, tmp_path):
     """3 samples, checkpoint to a file, a new frame object from the file, 4 more samples: the frame
     is the oracle's 7-sample frame bit for bit, and the intermediate frame its 3-sample frame."""
