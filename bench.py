@@ -9,16 +9,19 @@ HIP kernels through the C ABI (include/rt_gpu.h) into device memory.  The scene 
 in HBM before the timed region.  With N > 1 (one process per GPU, torch.distributed/RCCL)
 every frame is cut into 8-row bands dealt round-robin to the ranks; each rank renders its
 bands into a packed buffer and one all-gather over xGMI assembles the frame on every rank.
-The frame is the same whatever N is (the generator is keyed by pixel and sample), so this is
-strong scaling of a fixed frame.
+Frame i of a run is made of samples i*spp ... i*spp + spp - 1 of every pixel under one seed: the
+frames are independent and the same pictures whatever N is (the generator is keyed by pixel and
+sample), so this is strong scaling of fixed frames.
 
-Frames are independent, and the end of a frame is latency-bound (a few long paths, a few
-thousand rays per launch), so --frames-in-flight of them (default 3 or 4; 4 or 6 with N > 1) are rendered concurrently,
-each on its own stream with its own device work lists: the tail of frame i overlaps the
-machine-filling first launch of frame i+1 and, with N > 1, the all-gather of frame i overlaps
-rendering.  Every timed frame is complete (rendered, gathered, assembled) inside the timed
-region; ms_per_step is elapsed / K, not the latency of one frame (--frames-in-flight 1 gives
-that).
+The end of a frame is latency-bound (a few long paths, a few thousand rays per launch) and a
+1/N share of a frame makes small launches, so (a) with N > 1 one render call produces this
+rank's share of --frames-per-call consecutive frames (default min(N, 4); options.frames of the
+C ABI): launches as large as a whole frame's, one gather for all of them; (b) --frames-in-flight
+calls (default 3 or 4) run concurrently, each on its own stream with its own device work lists:
+the tail of one overlaps the machine-filling first launch of the next and, with N > 1, the
+all-gather overlaps rendering.  Every timed frame is complete (rendered, gathered, assembled)
+inside the timed region; ms_per_step is elapsed / K, not the latency of one frame
+(--frames-in-flight 1 --frames-per-call 1 gives that).
 
 Rank 0 prints one JSON line.  A frame is rendered by two kernels that alternate: rt_shade_kernel
 (path bookkeeping, sampling, the scene's lights/spheres/planes, instance root boxes) and
@@ -131,9 +134,6 @@ def main():
     ap.add_argument("--scene", default="dog_room")
     ap.add_argument("--max-segments", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--rehearse-ranks", type=int, default=0,
-                    help="single process, single GPU: act as rank 0 of this many ranks and render the other ranks' "
-                         "shares in place of the all-gather (a check of the multi-GPU path, not a measurement)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="torch.distributed backend: nccl (= RCCL over xGMI, one GPU per rank); gloo gathers through host "
                          "memory and lets several ranks share a GPU (a functional check of the multi-process path on a "
@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--split", choices=("bands", "samples"), default="bands",
                     help="how N devices share a frame: 8-row bands (bit-identical to one device) or sample ranges of "
                          "every pixel, summed in rank order (equal up to float summation order; for small frames)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--frames-per-call", type=int, default=0,
+                    help="frames whose shares one render call produces (0 = 1 on one GPU, min(N, 4) when N GPUs share a frame)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently, each with its own stream and device work lists "
                          "(0 = 3 or 4 on one GPU, 4 or 6 when the frame is shared by several, by the number of steps)")
@@ -170,65 +173,35 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-    elif args.rehearse_ranks > 1:
-        # One process plays rank 0 of N: the other ranks' shares are rendered here as well, inside
-        # the stand-in for the all-gather.  Exercises the band split, the packed buffers and the
-        # frame pipeline on a single GPU; the numbers it prints are not a benchmark.
-        world = args.rehearse_ranks
-
-        class RehearsalDist:
-            class ReduceOp:
-                MAX, SUM = "max", "sum"
-
-            def __init__(self):
-                self.scene, self.seed = None, 0
-
-            def all_gather_into_tensor(self, out, mine):
-                rows = mine.shape[0]
-                out[:rows].copy_(mine)
-                part = torch.empty_like(mine)
-                for r in range(1, world):
-                    count = args.spp
-                    if args.split == "samples":
-                        first, count = multi_gpu.sample_range(r, world, args.spp)
-                        o = gpu.Options(max_segments=args.max_segments, sample_offset=first, flags=gpu.FLAG_ACCUMULATE)
-                        part.zero_()
-                    else:
-                        o = gpu.Options(max_segments=args.max_segments, band_rows=multi_gpu.BAND_ROWS, band_rank=r,
-                                        band_count=world, flags=gpu.FLAG_COMPACT_BANDS)
-                    torch.cuda.synchronize()
-                    self.scene.render_region_device(part.data_ptr(), args.width, args.height,
-                                                    (0, 0, args.width, args.height), count, self.seed, o)
-                    torch.cuda.synchronize()
-                    out[r * rows:(r + 1) * rows].copy_(part)
-
-            def all_reduce(self, t, op=None):
-                pass
-
-            def barrier(self):
-                pass
-
-            def destroy_process_group(self):
-                pass
-        dist = RehearsalDist()
 
     W, H, spp = args.width, args.height, args.spp
     band = multi_gpu.BAND_ROWS
     sh = scenes.CONFIGS[args.scene]()
-    # more frames in flight overlap more, but the timed region starts and ends with a partly filled pipeline
+    by_samples = world > 1 and args.split == "samples"
+    my_spp = spp
+    # Frame i of a run = samples i*spp ... i*spp + spp - 1 of every pixel (one seed): independent frames
+    # that are the same pictures whatever N is.  When several GPUs share a frame, a call renders this
+    # rank's share of `per_call` consecutive frames at once (options.frames): launches as large as a whole
+    # frame's instead of 1/N of it, one gather for all of them.
+    if args.frames_per_call > 0:
+        per_call = args.frames_per_call
+    else:
+        per_call = 1 if (world == 1 or by_samples) else min(world, 4)
+    if by_samples:
+        per_call = 1
+    # more calls in flight overlap more, but the timed region starts and ends with a partly filled pipeline
+    calls = (args.steps + per_call - 1) // per_call
     if args.frames_in_flight > 0:
         in_flight = args.frames_in_flight
     elif world == 1:
         in_flight = 4 if args.steps >= 16 else 3
     else:
-        in_flight = 6 if args.steps >= 12 else 4
-    by_samples = world > 1 and args.split == "samples"
-    my_spp = spp
+        in_flight = max(2, min(4, calls))
 
-    # One "lane" per frame in flight: its own resident scene (with its own work lists on the device),
-    # stream and output buffers.  Frames are rendered by worker threads (the C call releases the GIL),
-    # so the latency-bound last rounds of frame i overlap the first, machine-filling launch of frame
-    # i+1; collectives stay on this thread, in frame order.
+    # One "lane" per call in flight: its own resident scene (with its own work lists on the device),
+    # stream and output buffers.  Calls are made by worker threads (the C call releases the GIL),
+    # so the latency-bound last rounds of one overlap the first, machine-filling launch of the next;
+    # collectives stay on this thread, in frame order.
     class Lane:
         pass
     lanes = []
@@ -238,67 +211,73 @@ def main():
         ln.stream = torch.cuda.Stream()
         if world > 1:
             rows = H if by_samples else multi_gpu.packed_rows(world, H, band)
-            ln.mine = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")
-            ln.gathered = torch.zeros((world * rows, W, 3), dtype=torch.float32, device="cuda")
+            ln.mine = torch.zeros((per_call, rows, W, 3), dtype=torch.float32, device="cuda")
+            ln.gathered = torch.zeros((world, per_call, rows, W, 3), dtype=torch.float32, device="cuda")
         else:
-            ln.mine = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+            ln.mine = torch.zeros((per_call, H, W, 3), dtype=torch.float32, device="cuda")
             ln.gathered = None
         lanes.append(ln)
+    first_sample = 0
     if by_samples:
         first_sample, my_spp = multi_gpu.sample_range(rank, world, spp)
-        opts = gpu.Options(max_segments=args.max_segments, sample_offset=first_sample, flags=gpu.FLAG_ACCUMULATE)
+        base = dict(max_segments=args.max_segments, flags=gpu.FLAG_ACCUMULATE)
     elif world > 1:
-        opts = gpu.Options(max_segments=args.max_segments, band_rows=band, band_rank=rank, band_count=world,
-                           flags=gpu.FLAG_COMPACT_BANDS)
+        base = dict(max_segments=args.max_segments, band_rows=band, band_rank=rank, band_count=world,
+                    flags=gpu.FLAG_COMPACT_BANDS)
     else:
-        opts = gpu.Options(max_segments=args.max_segments)
+        base = dict(max_segments=args.max_segments)
     g = lanes[0].g
     frame = None
     torch.cuda.synchronize()
 
-    if args.rehearse_ranks > 1:
-        dist.scene = gpu.GpuScene(sh)
-
-    def render(ln, seed, options):
-        ln.seed = seed
+    def render(ln, first_frame, count, extra_flags):
+        ln.count = count
         if by_samples:
             with torch.cuda.stream(ln.stream):
                 ln.mine.zero_()                        # this rank's samples are added to zeros
-        ln.g.render_region_device(ln.mine.data_ptr(), W, H, (0, 0, W, H), my_spp, seed, options, ln.stream.cuda_stream)
+        o = gpu.Options(**base)
+        o.flags |= extra_flags
+        o.sample_offset = first_frame * spp + first_sample
+        o.frames = count
+        ln.g.render_region_device(ln.mine.data_ptr(), W, H, (0, 0, W, H), my_spp, args.seed, o, ln.stream.cuda_stream)
 
-    def finish_frame(ln):
+    def finish_call(ln):
+        """Gather the shares of the call's frames and put every frame together (the last one stays in `frame`)."""
         nonlocal frame
         if world > 1:
             with torch.cuda.stream(ln.stream):
-                if args.rehearse_ranks > 1:
-                    dist.seed = ln.seed
-                if args.backend == "gloo" and args.rehearse_ranks <= 1:   # through host memory
+                flat_all, flat_mine = ln.gathered.view(-1, W, 3), ln.mine.view(-1, W, 3)
+                if args.backend == "gloo":               # through host memory
                     ln.stream.synchronize()
-                    host_all = torch.empty(ln.gathered.shape, dtype=torch.float32)
-                    dist.all_gather_into_tensor(host_all, ln.mine.cpu())
-                    ln.gathered.copy_(host_all)
+                    host_all = torch.empty(flat_all.shape, dtype=torch.float32)
+                    dist.all_gather_into_tensor(host_all, flat_mine.cpu())
+                    flat_all.copy_(host_all)
                 else:
-                    dist.all_gather_into_tensor(ln.gathered, ln.mine)
-                if by_samples:
-                    frame = multi_gpu.combine_partial_sums(ln.gathered, world, spp)
-                else:
-                    frame = multi_gpu.assemble(ln.gathered, world, H, W, band)
+                    dist.all_gather_into_tensor(flat_all, flat_mine)
+                for j in range(ln.count):
+                    shares = ln.gathered[:, j].reshape(-1, W, 3)          # (world * rows, W, 3)
+                    if by_samples:
+                        frame = multi_gpu.combine_partial_sums(shares, world, spp)
+                    else:
+                        frame = multi_gpu.assemble(shares, world, H, W, band)
         else:
-            frame = ln.mine
+            frame = ln.mine[ln.count - 1]
 
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=in_flight)
 
-    def run_frames(seeds, options=opts, depth=in_flight):
-        """Render one frame per seed, `depth` of them in flight."""
+    def run_frames(first_frame, count, extra_flags=0, depth=in_flight):
+        """Render frames first_frame ... first_frame + count - 1, `per_call` per call, `depth` calls in flight."""
+        todo = [(f, min(per_call, first_frame + count - f)) for f in range(first_frame, first_frame + count, per_call)]
         pending = {}
-        for j in range(min(depth, len(seeds))):
-            pending[j] = pool.submit(render, lanes[j % depth], seeds[j], options)
-        for i in range(len(seeds)):
+        for j in range(min(depth, len(todo))):
+            pending[j] = pool.submit(render, lanes[j % depth], todo[j][0], todo[j][1], extra_flags)
+        for i in range(len(todo)):
             pending.pop(i).result()
-            finish_frame(lanes[i % depth])
-            if i + depth < len(seeds):
-                pending[i + depth] = pool.submit(render, lanes[(i + depth) % depth], seeds[i + depth], options)
+            finish_call(lanes[i % depth])
+            if i + depth < len(todo):
+                k = i + depth
+                pending[k] = pool.submit(render, lanes[k % depth], todo[k][0], todo[k][1], extra_flags)
 
     def fence():
         torch.cuda.synchronize()
@@ -306,14 +285,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run_frames([20_000 + k for k in range(in_flight)])          # set-up: every lane allocates its device work lists
+    run_frames(20_000, in_flight * per_call)                    # set-up: every lane allocates its device work lists
     fence()
-    run_frames([10_000 + i for i in range(args.warmup)])
+    run_frames(10_000, args.warmup)
     fence()
     for ln in lanes:
         ln.g.reset_stats()
     t0 = time.perf_counter()
-    run_frames(list(range(args.steps)))
+    run_frames(0, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     rays = float(sum(ln.g.stats()["rays"] for ln in lanes))
@@ -321,7 +300,7 @@ def main():
     # kernel durations: frames rendered one at a time (HIP events around every launch; with frames
     # overlapping, an event pair would also span the other frame's kernels)
     g.reset_stats()
-    run_frames([0, 1, 2], depth=1)
+    run_frames(0, 3, depth=1)
     fence()
     st = g.stats()
     frames = 3                                       # (a frame is several launches when its samples come in batches)
@@ -339,10 +318,9 @@ def main():
     shade_ms = fresh_ms + resume_ms
     kernel_ms = shade_ms + tree_ms + finish_ms
 
-    # algorithmic bytes of ONE frame: the same frame (seed 0) with the detailed counters on, untimed
+    # algorithmic bytes of ONE frame: frame 0 again with the detailed counters on, untimed
     g.reset_stats()
-    run_frames([0], gpu.Options(max_segments=args.max_segments, flags=opts.flags | gpu.FLAG_DETAILED_STATS,
-                                sample_offset=opts.sample_offset, band_rows=opts.band_rows, band_rank=opts.band_rank, band_count=opts.band_count), depth=1)
+    run_frames(0, 1, extra_flags=gpu.FLAG_DETAILED_STATS, depth=1)
     torch.cuda.synchronize()
     det = g.stats()
     own_pixels = H * W if by_samples else (H // world) * W
@@ -376,7 +354,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "dog model + texture from the parsed-asset fixtures in tests/golden, room scene from the "
-                    "reference's main(); random numbers from the counter generator, seed = step index",
+                    "reference's main(); random numbers from the counter generator, one seed, frame i = samples i*spp ... of it",
             "config": {
                 "workload": f"{args.scene} {W}x{H} {spp} spp, {args.max_segments}-segment paths" +
                             (" (config 4: dog.obj textured, BVH, indirect lighting)" if args.scene == "dog_room" else ""),
@@ -385,7 +363,9 @@ def main():
                 "ms_per_frame": round(1e3 * elapsed / args.steps, 3),
                 "split": ("sample ranges + all-gather + sum in rank order" if by_samples else
                           "8-row bands round-robin + all-gather") if world > 1 else "single device",
-                "frames_in_flight": in_flight,
+                "frames_per_call": per_call,
+                "calls_in_flight": in_flight,
+                "frames_in_flight": in_flight * per_call,
                 "frame_checksum_seed0": checksum,
             },
             "roofline": {

@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
-"""Frames per second of one rank's share of the frame (WORLD ranks, default 8) with K frames in flight, K = 1..6."""
+"""Time per frame of one rank's share of the frame (WORLD ranks, default 8) with K calls in flight, K = 1..6,
+FRAMES frames per call (default 1)."""
 import os, sys, time
 from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raytracing_amd import gpu, scenes, multi_gpu
-W = H = 1024; spp = 64; world = int(os.environ.get("WORLD", "8"))
+W = H = 1024; spp = 64; world = int(os.environ.get("WORLD", "8")); per_call = int(os.environ.get("FRAMES", "1"))
 sh = scenes.dog_room()
 rows = multi_gpu.packed_rows(world, H, multi_gpu.BAND_ROWS)
-opts = gpu.Options(band_rows=multi_gpu.BAND_ROWS, band_rank=1, band_count=world, flags=gpu.FLAG_COMPACT_BANDS) if world > 1 else gpu.Options()
+def options(first):
+    o = gpu.Options(band_rows=multi_gpu.BAND_ROWS, band_rank=1, band_count=world, flags=gpu.FLAG_COMPACT_BANDS) if world > 1 else gpu.Options()
+    o.frames = per_call; o.sample_offset = first * spp
+    return o
 lanes = []
 for k in range(6):
-    lanes.append((gpu.GpuScene(sh), torch.cuda.Stream(), torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")))
+    lanes.append((gpu.GpuScene(sh), torch.cuda.Stream(), torch.zeros((per_call, rows, W, 3), dtype=torch.float32, device="cuda")))
 def render(k, seed):
     g, s, buf = lanes[k]
-    g.render_region_device(buf.data_ptr(), W, H, (0, 0, W, H), spp, seed, opts, s.cuda_stream)
+    g.render_region_device(buf.data_ptr(), W, H, (0, 0, W, H), spp, 0, options(seed * per_call), s.cuda_stream)
 for k in range(6): render(k, 100 + k)
 torch.cuda.synchronize()
 for K in (1, 2, 3, 4, 5, 6):
@@ -27,4 +31,4 @@ for K in (1, 2, 3, 4, 5, 6):
         if i + K < n: futs.append(pool.submit(render, (i + K) % K, i + K))
     torch.cuda.synchronize(); dt = time.perf_counter() - t
     pool.shutdown()
-    print(f"world {world}: {K} in flight: {1e3 * dt / n:.2f} ms per frame share")
+    print(f"world {world}: {per_call} frames per call, {K} calls in flight: {1e3 * dt / n / per_call:.2f} ms per frame share")
