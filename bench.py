@@ -145,8 +145,8 @@ def main():
     ap.add_argument("--frames-per-call", type=int, default=0,
                     help="frames whose shares one render call produces (0 = 1 on one GPU, min(N, 4) when N GPUs share a frame)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames rendered concurrently, each with its own stream and device work lists "
-                         "(0 = 3 or 4 on one GPU, 4 or 6 when the frame is shared by several, by the number of steps)")
+                    help="render calls running concurrently, each with its own stream and device work lists "
+                         "(0 = 3 or 4 on one GPU by the number of steps, 2 to 4 when several GPUs share the frames)")
     args = ap.parse_args()
 
     # every frame in flight has its own stream; HIP maps streams onto 4 hardware queues unless told otherwise,
