@@ -123,3 +123,17 @@ int render_with_gpu(Scene *scene, Image3f *images, int count)
                         "-I", os.path.join(ROOT, "include"), "-w"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
     assert obj.stat().st_size > 0
+
+
+def test_options_and_stats_records_match_the_c_header(tmp_path):
+    """rt_gpu_options / rt_gpu_stats as C lays them out against the ctypes mirrors in raytracing_amd/gpu.py."""
+    src = tmp_path / "opts.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rt_gpu.h"\nint main(void){'
+                   'printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(rt_gpu_options), offsetof(rt_gpu_options, frames), '
+                   'offsetof(rt_gpu_options, frame_stride), sizeof(rt_gpu_stats), offsetof(rt_gpu_stats, kernel_ms), '
+                   'offsetof(rt_gpu_stats, launches)); return 0;}\n')
+    exe = tmp_path / "opts"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], stdout=subprocess.PIPE, check=True).stdout.split()]
+    assert got == [C.sizeof(gpu.Options), gpu.Options.frames.offset, gpu.Options.frame_stride.offset,
+                   C.sizeof(gpu.Stats), gpu.Stats.kernel_ms.offset, gpu.Stats.launches.offset]
