@@ -14,7 +14,8 @@ Variants of the compiled reference:
 The dog model sits in the reference as a zip; it is unpacked to a scratch directory outside the
 repository, parsed by the reference's own fast_obj and stored as arrays (dog_obj.npz); the
 texture JPEG is decoded by the reference's own stb_image and stored as bytes
-(dog_texture_rgb8.npz).
+(dog_texture_rgb8.npz).  The cat model (the second mesh of the 4096 x 4096 configuration) goes the
+same way.  These parsed assets are what the package's scenes load (raytracing_amd/assets/).
 """
 import ctypes as C
 import hashlib
@@ -32,42 +33,57 @@ import _libs as L  # noqa: E402
 from raytracing_amd import host, scenes, scene_types as T  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
+ASSETS = os.path.join(ROOT, "raytracing_amd", "assets")
 WORK = "/tmp/rt_ref_work"
 REF_MODELS = "/root/reference/models"
 DOG_DIR = "Australian_Cattle_Dog_v1_L3.123c9c6a5764-399b-4e86-9897-6bcb08b5e8ed"
+CAT_DIR = "Cat_v1_L3.123cb1b1943a-2f48-4e44-8f71-6bbe19a3ab64"
+# model name -> (zip, member pattern, diffuse map)
+MODELS = {
+    "dog": ("dog.zip", "*/13463_Australian_Cattle_Dog_v3.obj", os.path.join(DOG_DIR, "Australian_Cattle_Dog_dif.jpg")),
+    "cat": (CAT_DIR + ".zip", "*/12221_Cat_v1_l3.obj", os.path.join(CAT_DIR, "Cat_diffuse.jpg")),
+}
 
 
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def unpack_dog():
+def unpack_model(name):
     os.makedirs(os.path.join(WORK, "models"), exist_ok=True)
-    dst = os.path.join(WORK, "models", "dog.obj")
+    dst = os.path.join(WORK, "models", name + ".obj")
     if not os.path.exists(dst):
-        data = subprocess.run(["unzip", "-p", os.path.join(REF_MODELS, "dog.zip"),
-                               "*/13463_Australian_Cattle_Dog_v3.obj"], stdout=subprocess.PIPE, check=True).stdout
+        archive, member, _ = MODELS[name]
+        data = subprocess.run(["unzip", "-p", os.path.join(REF_MODELS, archive), member],
+                              stdout=subprocess.PIPE, check=True).stdout
         with open(dst, "wb") as f:
             f.write(data)
     return dst
 
 
+def unpack_dog():
+    return unpack_model("dog")
+
+
 def assets():
     R = L.ref("strict")
-    a = L.RefObjArrays()
-    assert R.ref_fast_obj_read(unpack_dog().encode(), C.byref(a)) == 0
-    pos = np.ctypeslib.as_array(a.positions, shape=(a.position_count * 3,)).copy().reshape(-1, 3)
-    tc = np.ctypeslib.as_array(a.texcoords, shape=(a.texcoord_count * 2,)).copy().reshape(-1, 2)
-    nr = np.ctypeslib.as_array(a.normals, shape=(a.normal_count * 3,)).copy().reshape(-1, 3)
-    fv = np.ctypeslib.as_array(a.face_vertices, shape=(a.face_count,)).copy()
-    idx = np.ctypeslib.as_array(a.indices, shape=(a.index_count * 3,)).copy().reshape(-1, 3)
-    np.savez_compressed(os.path.join(GOLD, "dog_obj.npz"), positions=pos, texcoords=tc, normals=nr,
-                        face_vertices=fv.astype(np.uint8), indices=idx)
-    w, h = C.c_int(), C.c_int()
-    jpg = os.path.join(REF_MODELS, DOG_DIR, "Australian_Cattle_Dog_dif.jpg")
-    p = R.ref_stbi_load_rgb(jpg.encode(), C.byref(w), C.byref(h))
-    rgb = np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
-    np.savez_compressed(os.path.join(GOLD, "dog_texture_rgb8.npz"), rgb=rgb)
+    os.makedirs(ASSETS, exist_ok=True)
+    for name, (_, _, jpg_rel) in MODELS.items():
+        a = L.RefObjArrays()
+        assert R.ref_fast_obj_read(unpack_model(name).encode(), C.byref(a)) == 0
+        pos = np.ctypeslib.as_array(a.positions, shape=(a.position_count * 3,)).copy().reshape(-1, 3)
+        tc = np.ctypeslib.as_array(a.texcoords, shape=(a.texcoord_count * 2,)).copy().reshape(-1, 2)
+        nr = np.ctypeslib.as_array(a.normals, shape=(a.normal_count * 3,)).copy().reshape(-1, 3)
+        fv = np.ctypeslib.as_array(a.face_vertices, shape=(a.face_count,)).copy()
+        idx = np.ctypeslib.as_array(a.indices, shape=(a.index_count * 3,)).copy().reshape(-1, 3)
+        np.savez_compressed(os.path.join(ASSETS, name + "_obj.npz"), positions=pos, texcoords=tc, normals=nr,
+                            face_vertices=fv.astype(np.uint8), indices=idx)
+        w, h = C.c_int(), C.c_int()
+        p = R.ref_stbi_load_rgb(os.path.join(REF_MODELS, jpg_rel).encode(), C.byref(w), C.byref(h))
+        rgb = np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
+        np.savez_compressed(os.path.join(ASSETS, name + "_texture_rgb8.npz"), rgb=rgb)
+        print(f"  {name}: {len(pos)} v, {len(tc)} vt, {len(nr)} vn, {len(fv)} faces (vertices per face: "
+              f"{sorted(set(fv.tolist()))}), texture {w.value}x{h.value}")
 
 
 def host_stage_fixture():
@@ -104,8 +120,21 @@ def host_stage_fixture():
     arr.reshape(-1)[:] = vals
     q = np.zeros(len(vals), np.uint8)
     assert R.ref_quantize_image(C.byref(img), os.path.join(WORK, "q.png").encode(), q.ctypes.data) == 0
+    # the cat through the same loaders
+    os.chdir(WORK)
+    unpack_model("cat")
+    cat = T.Mesh()
+    R.ref_load_mesh(b"models/cat.obj", C.byref(cat))
+    os.chdir(cwd)
+    cat_census = (C.c_uint32 * 4)()
+    R.ref_bvh_census(C.byref(cat), C.byref(cat_census))
+    cat_tex = T.Image3f()
+    R.ref_load_texture(os.path.join(REF_MODELS, MODELS["cat"][2]).encode(), C.byref(cat_tex))
     np.savez_compressed(
         os.path.join(GOLD, "host_stages.npz"),
+        cat_census=np.array(list(cat_census), np.uint32), cat_tree_depth=np.uint32(cat.tree_depth),
+        cat_tree_sha=sha(host.mesh_dump_tree(cat)), cat_faces_sha=sha(host.mesh_faces_array(cat)),
+        cat_texture_sha=sha(host.image_as_array(cat_tex)),
         census=np.array(list(census), np.uint32), tree_depth=np.uint32(mesh.tree_depth),
         tree_sha=sha(tree), faces_sha=sha(faces), root_bbox=tree[0, :6].view(np.float32),
         tree_head=tree[:64], texture_sha=sha(texels), texture_uv=uv, texture_probes=probes,
@@ -198,7 +227,8 @@ def probe_rays(scene_name, n, seed):
 def hit_fixture():
     R = L.ref("strict")
     out = {}
-    for name, n in (("sphere_room", 1024), ("dog_room", 2048), ("three_dogs", 2048), ("deux_spheres", 512)):
+    for name, n in (("sphere_room", 1024), ("dog_room", 2048), ("three_dogs", 2048), ("deux_spheres", 512),
+                    ("dogs_and_cat", 2048)):
         sh = scenes.CONFIGS[name]()
         rays = probe_rays(name, n, 17)
         for tag, maxd in (("inf", 3.4028234663852886e38), ("d60", 60.0)):
@@ -228,7 +258,7 @@ def region_fixture():
     job k seeded with serie_from_seed(500 + k), for each scene and each reference variant."""
     out = {}
     size, tile, spp = 40, 8, 2
-    for name in ("deux_spheres", "sphere_room", "diffuse_room", "dog_room", "three_dogs"):
+    for name in ("deux_spheres", "sphere_room", "diffuse_room", "dog_room", "three_dogs", "dogs_and_cat"):
         sh = scenes.CONFIGS[name]()
         for variant in ("build", "strict", "strict_pm"):
             img, arr = host.new_image(size, size)
@@ -244,7 +274,7 @@ def converged_fixture():
     out = {}
     size, spp, tile = 128, 256, 16
     threads = min(8, os.cpu_count() or 1)
-    for name in ("sphere_room", "dog_room", "three_dogs", "deux_spheres"):
+    for name in ("sphere_room", "dog_room", "three_dogs", "deux_spheres", "diffuse_room", "dogs_and_cat"):
         sh = scenes.CONFIGS[name]()
         img, arr = host.new_image(size, size)
         ntiles = (size // tile) ** 2
@@ -255,6 +285,27 @@ def converged_fixture():
         out[name + "_nan"] = np.int64(np.isnan(arr).sum())
     out["size"], out["spp"], out["tile"] = size, spp, tile
     np.savez_compressed(os.path.join(GOLD, "converged_stats.npz"), **out)
+
+
+def converged_pair_fixture():
+    """Two renders of every scene by the reference at its build.sh flags, same size and sample
+    count, independent generator seeds (one Random_Serie per 16x16 tile, as thread_entry_point
+    seeds its tiles): the reference's own run-to-run spread is the yardstick for "the same
+    picture at equal sample count"."""
+    out = {}
+    size, spp, tile = 96, 256, 16
+    threads = min(8, os.cpu_count() or 1)
+    ntiles = (size // tile) ** 2
+    for name in ("deux_spheres", "sphere_room", "diffuse_room", "dog_room", "three_dogs", "dogs_and_cat"):
+        sh = scenes.CONFIGS[name]()
+        for tag, seed0 in (("a", 70000), ("b", 80000)):
+            img, arr = host.new_image(size, size)
+            seeds = (T.RandomSerie * ntiles)(*[L.serie_from_seed(seed0 + i) for i in range(ntiles)])
+            t = L.ref("build").ref_render_tiles(sh.ptr, C.byref(img), spp, tile, threads, seeds)
+            out[f"{name}_{tag}"] = arr.copy()
+            print(f"  {name} {tag}: {t:.1f} s, mean {np.nanmean(arr):.5f}, NaN {int(np.isnan(arr).sum())}", flush=True)
+    out["size"], out["spp"], out["tile"] = size, spp, tile
+    np.savez_compressed(os.path.join(GOLD, "converged_pairs.npz"), **out)
 
 
 def math_fixture():
@@ -273,9 +324,9 @@ def math_fixture():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    todo = sys.argv[1:] or ["assets", "host", "rng", "hit", "region", "converged", "math"]
+    todo = sys.argv[1:] or ["assets", "host", "rng", "hit", "region", "converged", "pairs", "math"]
     steps = dict(assets=assets, host=host_stage_fixture, rng=rng_fixture, hit=hit_fixture,
-                 region=region_fixture, converged=converged_fixture, math=math_fixture)
+                 region=region_fixture, converged=converged_fixture, pairs=converged_pair_fixture, math=math_fixture)
     for name in todo:
         print("golden:", name, flush=True)
         steps[name]()

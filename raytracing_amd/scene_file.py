@@ -113,15 +113,28 @@ def load(source, base_dir=None):
     return scenes.SceneHandle(doc.get("name", "scene"), camera, mats, spheres, planes, lights, instances, keep=keep)
 
 
-def describe(handle, textures=None, meshes=None):
-    """The document of a SceneHandle whose instances use at most one mesh and one texture, given
-    the files those came from ({"name": "file.npz"}).  Floats are written with 9 significant
-    digits, which a C float survives unchanged."""
+def describe(handle, textures=None, meshes=None, objects=None):
+    """The document of a SceneHandle, given the files its textures and meshes came from
+    ({"name": "file.npz"}).  A scene with several meshes or textures also needs `objects`
+    ({"name": the Mesh or Image3f record the scene points at}) to tell which is which; with one
+    of each the only name is used.  Floats are written with 9 significant digits, which a C float
+    survives unchanged."""
+    import ctypes as C
+
     def v(x):
         return [float(np.float32(x.x)), float(np.float32(x.y)), float(np.float32(x.z))]
     s = handle.scene
-    tex_name = next(iter(textures)) if textures else None
-    mesh_name = next(iter(meshes)) if meshes else None
+    by_address = {C.addressof(obj): name for name, obj in (objects or {}).items()}
+
+    def name_of(pointer, names, what):
+        if not pointer:
+            raise SceneFileError(f"{what}: null pointer")
+        address = C.addressof(pointer.contents)
+        if address in by_address:
+            return by_address[address]
+        if names and len(names) == 1:
+            return next(iter(names))
+        raise SceneFileError(f"{what}: cannot tell which file it came from (pass objects=)")
     mats = []
     for i in range(s.material_count):
         m = s.materials[i]
@@ -132,7 +145,7 @@ def describe(handle, textures=None, meshes=None):
         else:
             d = {"diffuse": v(m.diffuse_color)}
             if m.textured:
-                d["texture"] = tex_name
+                d["texture"] = name_of(m.texture, textures, f"materials[{i}].texture")
             mats.append(d)
     doc = {
         "name": handle.name,
@@ -148,7 +161,7 @@ def describe(handle, textures=None, meshes=None):
                    for i in range(s.light_count)],
         "textures": dict(textures or {}),
         "meshes": dict(meshes or {}),
-        "instances": [{"mesh": mesh_name, "position": v(s.meshes[i].transform.position),
+        "instances": [{"mesh": name_of(s.meshes[i].mesh, meshes, f"instances[{i}].mesh"), "position": v(s.meshes[i].transform.position),
                        "material": int(s.meshes[i].material_id),
                        "mirrored_x": bool(s.meshes[i].transform.rotX.x < 0)} for i in range(s.mesh_count)],
     }

@@ -3,8 +3,8 @@
 The host program hard-codes its scene in main() (reference: src/main.c:885-1054);
 the numbers below are that scene's data (materials :885-929, the optional
 spheres :933-947, planes :951-977, lights :979-992, mesh instances :996-1030,
-camera :1033-1038), regrouped into the five configurations the benchmark
-names.  Everything is plain data in ctypes records: no rendering logic here.
+camera :1033-1038), regrouped into the configurations the benchmark
+names (plus one with the second model, the cat).  Everything is plain data in ctypes records: no rendering logic here.
 """
 import ctypes as C
 import math
@@ -15,7 +15,7 @@ import numpy as np
 from . import scene_types as T
 from . import host
 
-GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 
 WHITE, BLACK = (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)
 RED, GREEN, BLUE = (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)
@@ -121,22 +121,40 @@ def instance(mesh, position, material_id, mirrored_x=False):
 _ASSET_CACHE = {}
 
 
+def _load_mesh(name):
+    if name not in _ASSET_CACHE:
+        with np.load(os.path.join(ASSET_DIR, name + "_obj.npz"), allow_pickle=False) as z:
+            _ASSET_CACHE[name] = host.mesh_from_obj_arrays(
+                z["positions"], z["texcoords"], z["normals"], z["indices"], z["face_vertices"])
+    return _ASSET_CACHE[name]
+
+
+def _load_texture(name):
+    key = name + "_texture"
+    if key not in _ASSET_CACHE:
+        with np.load(os.path.join(ASSET_DIR, name + "_texture_rgb8.npz"), allow_pickle=False) as z:
+            _ASSET_CACHE[key] = host.texture_from_rgb8(z["rgb"])
+    return _ASSET_CACHE[key]
+
+
 def load_dog_mesh():
-    """The dog model (71 968 triangles) from the parsed-OBJ fixture, triangulated and
+    """The dog model (71 968 triangles) from its parsed-OBJ arrays, triangulated and
     given its box tree by the host C code (include/rt_host.h)."""
-    if "dog" not in _ASSET_CACHE:
-        z = np.load(os.path.join(GOLDEN_DIR, "dog_obj.npz"))
-        _ASSET_CACHE["dog"] = host.mesh_from_obj_arrays(
-            z["positions"], z["texcoords"], z["normals"], z["indices"], z["face_vertices"])
-    return _ASSET_CACHE["dog"]
+    return _load_mesh("dog")
 
 
 def load_dog_texture():
-    """The dog's diffuse map (decoded 8-bit RGB fixture), linearised by the host C code."""
-    if "dogtex" not in _ASSET_CACHE:
-        z = np.load(os.path.join(GOLDEN_DIR, "dog_texture_rgb8.npz"))
-        _ASSET_CACHE["dogtex"] = host.texture_from_rgb8(z["rgb"])
-    return _ASSET_CACHE["dogtex"]
+    """The dog's diffuse map (decoded 8-bit RGB), linearised by the host C code."""
+    return _load_texture("dog")
+
+
+def load_cat_mesh():
+    """The cat model (70 576 triangles), the second mesh of the 4096 x 4096 configuration."""
+    return _load_mesh("cat")
+
+
+def load_cat_texture():
+    return _load_texture("cat")
 
 
 # --------------------------------------------------------------------------- configurations
@@ -187,10 +205,29 @@ def three_dogs(mesh=None, texture=None):
                        room_lights(), meshes, keep=[mesh, texture])
 
 
+def dogs_and_cat():
+    """Config 5 as the benchmark list words it (dog + cat meshes + mirrors): two distinct meshes, two
+    textures, four instances (mirror dog mirrored in x, textured dog, textured cat, glass cat) and
+    the mirror sphere of the room.  The reference's source has no such scene (its main() instances the
+    dog three times and never loads the cat), so the placement is this build's; both models go
+    through the same loader (src/main.c:177-262)."""
+    dog, cat = load_dog_mesh(), load_cat_mesh()
+    dog_tex, cat_tex = load_dog_texture(), load_cat_texture()
+    mats = room_materials(dog_tex) + [_material(diffuse=WHITE, texture=cat_tex)]     # 9: the cat's diffuse map
+    meshes = [instance(dog, (-30.0, -10.0, 0.0), 5, mirrored_x=True),
+              instance(dog, (25.0, -10.0, 10.0), 8),
+              instance(cat, (-5.0, -10.0, -30.0), 9),
+              instance(cat, (0.0, -10.0, 35.0), 7)]
+    spheres = [T.Sphere(T.Vec3f(-8.0, 10.0, 15.0), 5.0, 5)]
+    return SceneHandle("dogs_and_cat", room_camera(), mats, spheres, room_planes(), room_lights(), meshes,
+                       keep=[dog, cat, dog_tex, cat_tex])
+
+
 CONFIGS = {
     "deux_spheres": deux_spheres,
     "sphere_room": sphere_room,
     "diffuse_room": diffuse_room,
     "dog_room": dog_room,
     "three_dogs": three_dogs,
+    "dogs_and_cat": dogs_and_cat,
 }

@@ -29,6 +29,20 @@ def test_dog_tree_matches_the_reference_node_for_node(golden):
     assert L.same_bits(tree[0, :6].view(np.float32), g["root_bbox"]).all()
 
 
+def test_cat_tree_matches_the_reference(golden):
+    """The second model through the same loader (src/main.c:177-262): census, tree and face
+    permutation equal to what the reference's load_mesh built from the same file."""
+    g = golden("host_stages")
+    mesh = scenes.load_cat_mesh()
+    cen = host.mesh_census(mesh)
+    assert [cen["nodes"], cen["leaves"], cen["depth"], cen["max_leaf"]] == list(g["cat_census"]) == [12955, 6478, 28, 16]
+    assert mesh.face_count == 70576 and mesh.tree_depth == int(g["cat_tree_depth"]) == 28
+    assert sha(host.mesh_dump_tree(mesh)) == str(g["cat_tree_sha"])
+    assert sha(host.mesh_faces_array(mesh)) == str(g["cat_faces_sha"])
+    tex = host.image_as_array(scenes.load_cat_texture())
+    assert tex.shape == (1024, 1024, 3) and sha(tex) == str(g["cat_texture_sha"])
+
+
 def test_small_meshes_and_polygons():
     """A quad becomes (0,1,2),(0,2,3); a pentagon fans; 17 triangles split once; 16 stay a leaf."""
     pos = np.array([[0, 0, 0], [0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [-1, 0.5, 0]], np.float32)

@@ -120,7 +120,7 @@ def check_results(res, g, prefix, n):
             assert (got[f] == want).all(), (prefix, f)
 
 
-@pytest.mark.parametrize("name", ["deux_spheres", "sphere_room", "dog_room", "three_dogs"])
+@pytest.mark.parametrize("name", ["deux_spheres", "sphere_room", "dog_room", "three_dogs", "dogs_and_cat"])
 @pytest.mark.parametrize("tag,maxd", [("inf", FLT_MAX), ("d60", 60.0)])
 def test_find_ray_hit_known_answers(golden, name, tag, maxd):
     """find_ray_hit (src/main.c:264-538): every field of Ray_Result for probe rays, including
@@ -147,7 +147,7 @@ def render_jobs_with_oracle(sh, size, tile, spp, seed0, math, lib=None):
     return arr
 
 
-@pytest.mark.parametrize("name", ["deux_spheres", "sphere_room", "diffuse_room", "dog_room", "three_dogs"])
+@pytest.mark.parametrize("name", ["deux_spheres", "sphere_room", "diffuse_room", "dog_room", "three_dogs", "dogs_and_cat"])
 @pytest.mark.parametrize("variant,math", [("strict", L.MATH_LIBM), ("strict_pm", L.MATH_PORTABLE)])
 def test_raytrace_region_known_answers(golden, name, variant, math):
     """raytrace_region (src/main.c:742-792) float buffers, bit for bit, for 25 jobs per scene."""

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.skipif(not (L.have_ref("strict") and L.have_ref("strict
                                 reason="compiled reference not present")
 
 
-@pytest.mark.parametrize("name", ["sphere_room", "dog_room", "three_dogs"])
+@pytest.mark.parametrize("name", ["sphere_room", "dog_room", "three_dogs", "dogs_and_cat"])
 @pytest.mark.parametrize("variant,math", [("strict", L.MATH_LIBM), ("strict_pm", L.MATH_PORTABLE)])
 def test_whole_region_single_job(name, variant, math):
     """One Job over the whole image (the reference's deterministic single-thread mode)."""

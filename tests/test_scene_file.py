@@ -10,6 +10,8 @@ import _libs as L
 from raytracing_amd import gpu, host, scene_file, scenes
 
 DOG_FILES = dict(textures={"dog_diffuse": "dog_texture_rgb8.npz"}, meshes={"dog": "dog_obj.npz"})
+BOTH_FILES = dict(textures={"dog_diffuse": "dog_texture_rgb8.npz", "cat_diffuse": "cat_texture_rgb8.npz"},
+                  meshes={"dog": "dog_obj.npz", "cat": "cat_obj.npz"})
 
 
 def _bytes(array, count):
@@ -27,10 +29,13 @@ def _render(sh, W=24, H=16, spp=2, seed=5):
 def test_document_round_trip_gives_the_same_records_and_the_same_picture(name, tmp_path):
     sh = scenes.CONFIGS[name]()
     files = DOG_FILES if sh.scene.mesh_count else {}
+    if name == "dogs_and_cat":
+        files = dict(BOTH_FILES, objects={"dog": scenes.load_dog_mesh(), "cat": scenes.load_cat_mesh(),
+                                          "dog_diffuse": scenes.load_dog_texture(), "cat_diffuse": scenes.load_cat_texture()})
     text = json.dumps(scene_file.describe(sh, **files))
     path = tmp_path / "scene.json"
     path.write_text(text)
-    back = scene_file.load(str(path), base_dir=scenes.GOLDEN_DIR)
+    back = scene_file.load(str(path), base_dir=scenes.ASSET_DIR)
     a, b = sh.scene, back.scene
     assert bytes(a.camera) == bytes(b.camera)
     for field, count in (("spheres", a.sphere_count), ("planes", a.plane_count), ("lights", a.light_count)):
@@ -45,6 +50,9 @@ def test_document_round_trip_gives_the_same_records_and_the_same_picture(name, t
         assert bytes(a.meshes[i].transform) == bytes(b.meshes[i].transform)
         assert a.meshes[i].material_id == b.meshes[i].material_id
         assert a.meshes[i].mesh.contents.face_count == b.meshes[i].mesh.contents.face_count
+    if name == "dogs_and_cat":      # two meshes, two textures: each instance and material got its own back
+        assert [b.meshes[i].mesh.contents.face_count for i in range(4)] == [71968, 71968, 70576, 70576]
+        assert C.addressof(b.materials[8].texture.contents) != C.addressof(b.materials[9].texture.contents)
     assert L.same_bits(_render(sh), _render(back)).all()
 
 
