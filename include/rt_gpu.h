@@ -139,6 +139,22 @@ int rt_gpu_render_region_device(rt_gpu_scene *scene, float *device_pixels, uint3
                                 rt_rect2u region, uint32_t spp, uint64_t seed,
                                 const rt_gpu_options *options, void *hip_stream);
 
+/* The same render as rt_gpu_render_region_device for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  The call makes no hipMalloc / hipFree / event creation and no
+ * read-back: the kernels' work memory (queue counters, per-sample values, the list of paths in
+ * transit) is a 15 MB array that is part of the library's code object, one copy per GPU, held until
+ * the process ends.  Limit: (8x8 pixel blocks of the region) x 64 x spp <= 65536 paths, e.g. a 64x64
+ * tile (the reference's tile size, src/main.c:794-824) at 16 samples per pixel; larger calls fail
+ * with RT_GPU_ERR_ARGUMENT.  options.frames must be 0 or 1; the other options (sample_offset,
+ * spp_total, ACCUMULATE, bands) work as above, so a frame of any sample count can be accumulated
+ * from several calls.  Same pixels as rt_gpu_render_region_device, bit for bit.  All calls on one
+ * GPU share that GPU's array: calls that overlap in time on one GPU (different streams or threads)
+ * race; calls on one stream are ordered and safe. */
+int rt_gpu_render_region_static(rt_gpu_scene *scene, float *device_pixels, uint32_t width, uint32_t height,
+                                rt_rect2u region, uint32_t spp, uint64_t seed,
+                                const rt_gpu_options *options, void *hip_stream);
+
 /* Multiply un-normalised sums (RT_GPU_FLAG_ACCUMULATE) by the reference's
  * final factor 1/(0.5*0.5*2*pi*spp_total) (src/main.c:788). */
 int rt_gpu_normalize_device(float *device_pixels, size_t pixel_count, uint32_t spp_total, void *hip_stream);

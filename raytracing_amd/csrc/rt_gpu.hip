@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -674,6 +675,7 @@ rt_tree_kernel(const TreeParams P)
 struct FinishParams {
     rt_dev_scene S;
     const uint32_t *list; uint32_t slots;
+    const uint32_t *slots_reserved;  /* not NULL: the slots the shade launch reserved, still in device memory (capped by `slots`) */
     float *samples; uint64_t *stats; QueueCounters *q;
     uint32_t seed0, seed1;
     int max_segments;
@@ -695,6 +697,11 @@ rt_finish_kernel(const FinishParams P)
     uint32_t sample_index = 0;
     uint32_t in_cur = 0, in_end = 0;
     bool input_done = false;
+    uint32_t slots = P.slots;
+    if (P.slots_reserved) {
+        const uint32_t r = __builtin_amdgcn_readfirstlane(*P.slots_reserved);
+        if (r < slots) slots = r;
+    }
     pm.phase = rt::PH_DEAD;
     pm.run(RT_SHADE_WEIGHT,
         [&]() {                                          /* a path ended */
@@ -711,8 +718,8 @@ rt_finish_kernel(const FinishParams P)
                     uint32_t v = 0;
                     if (lane == 0) v = atomicAdd(&P.q->in_next, 64u);
                     in_cur = __builtin_amdgcn_readfirstlane(v);
-                    if (in_cur >= P.slots) { input_done = true; break; }
-                    in_end = in_cur + 64u < P.slots ? in_cur + 64u : P.slots;
+                    if (in_cur >= slots) { input_done = true; break; }
+                    in_end = in_cur + 64u < slots ? in_cur + 64u : slots;
                 }
                 const uint32_t idx = in_cur + (uint32_t)__popcll(need & lanes_below);
                 if (pm.phase == rt::PH_DEAD && idx < in_end &&
@@ -972,6 +979,40 @@ static int fail(int code, const std::string &what)
             return fail(RT_GPU_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+/* ---- work memory of rt_gpu_render_region_static: one array per GPU, part of the code object ----
+ * Layout (byte offsets): the two queue-counter records (256 each), the per-sample values
+ * (12 bytes per path), then one parked list (192 bytes per slot).  `rt_static_scratch` is only a
+ * name on the host: the array's address on a device comes from hipGetSymbolAddress, once per device
+ * (static_scratch_of), and that pointer is what kernels and memsets get. */
+#define RT_STATIC_MAX_PATHS 65536u                       /* (8x8 pixel blocks of the region) x 64 x samples per pixel */
+#define RT_STATIC_LIST_SLOTS (RT_STATIC_MAX_PATHS + 8192u)   /* + one partly used 64-slot chunk for each of at most 128 waves */
+#define RT_STATIC_SAMPLES_AT 512u
+#define RT_STATIC_LIST_AT (RT_STATIC_SAMPLES_AT + RT_STATIC_MAX_PATHS * 12u)
+#define RT_STATIC_BYTES (RT_STATIC_LIST_AT + (size_t)RT_STATIC_LIST_SLOTS * RT_RECORD_WORDS * 4u)
+static __device__ __align__(256) unsigned char rt_static_scratch[RT_STATIC_BYTES];
+static_assert(RT_STATIC_LIST_AT % 256 == 0, "the parked list starts on a 256-byte boundary");
+
+#define RT_MAX_DEVICES 64
+static std::mutex g_static_mutex;
+static unsigned char *g_static_ptr[RT_MAX_DEVICES];     /* device address of rt_static_scratch on device i (NULL: not asked yet) */
+
+/* address of this device's copy of the array; the device must be current */
+static int static_scratch_of(int device, unsigned char **out)
+{
+    *out = nullptr;
+    if (device < 0 || device >= RT_MAX_DEVICES) return fail(RT_GPU_ERR_ARGUMENT, "device index above 63");
+    std::lock_guard<std::mutex> guard(g_static_mutex);
+    if (!g_static_ptr[device]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(rt_static_scratch));
+        if (e != hipSuccess || !p)
+            return fail(RT_GPU_ERR_DEVICE, std::string("hipGetSymbolAddress(rt_static_scratch): ") + hipGetErrorString(e));
+        g_static_ptr[device] = static_cast<unsigned char *>(p);
+    }
+    *out = g_static_ptr[device];
+    return 0;
+}
+
 struct rt_gpu_scene {
     int device = 0;
     rt_dev_scene dev;
@@ -1149,6 +1190,10 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
             s->shade_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_shade);
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
+        }
+        {   /* this device's address of the static work memory (rt_gpu_render_region_static), asked once per device */
+            unsigned char *unused = nullptr;
+            if ((rc = static_scratch_of(s->device, &unused))) break;
         }
         std::vector<uint32_t> table(256);
         build_aes_table(table.data());
@@ -1481,6 +1526,113 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     }
     if (s->timers.size() + s->tree_timers.size() > 4096) settle_timers(s);
     s->samples += total_spp * own_rows * region.size.x;
+    return RT_GPU_OK;
+}
+
+/* The render of rt_gpu_render_region_device for callers that may not allocate: every buffer the
+ * kernels need beyond the caller's pixels lives in rt_static_scratch, and the launch sequence is
+ * fixed (new paths -> the in-wave finishing kernel for every parked path -> per-pixel sums): no
+ * read-back, no events, no hipMalloc / hipFree.  The finishing kernel learns how many slots the
+ * first launch reserved from the counter record in device memory. */
+int rt_gpu_render_region_static(rt_gpu_scene *s, float *device_pixels, uint32_t width, uint32_t height,
+                                rt_rect2u region, uint32_t spp, uint64_t seed,
+                                const rt_gpu_options *o, void *hip_stream)
+{
+    if (!s || !device_pixels) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_render_region_static: NULL argument");
+    if (o && o->struct_size != sizeof(rt_gpu_options)) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_options.struct_size mismatch");
+    if (!width || !height || !region.size.x || !region.size.y || !spp) return fail(RT_GPU_ERR_ARGUMENT, "empty image, region or sample count");
+    if ((uint64_t)region.point.x + region.size.x > width || (uint64_t)region.point.y + region.size.y > height)
+        return fail(RT_GPU_ERR_ARGUMENT, "region exceeds the image");
+    if (width > 0xFFFFu || height > 0xFFFFu) return fail(RT_GPU_ERR_ARGUMENT, "image sides above 65535 are not supported");
+    if (o && o->frames > 1) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_render_region_static renders one frame per call");
+    if ((uint64_t)spp + (o ? o->sample_offset : 0) > 0xFFFFFFFFull) return fail(RT_GPU_ERR_ARGUMENT, "sample indices exceed 32 bits");
+    RenderParams G;
+    memset(&G, 0, sizeof(G));
+    uint32_t own_rows = 0;
+    int rc = launch_geometry(o, region, G, &own_rows);
+    if (rc) return rc;
+    if (G.block_rows == 0) return RT_GPU_OK;
+    const uint64_t units = (uint64_t)G.blocks_x * G.block_rows;
+    const uint64_t paths = units * 64 * spp;
+    if (paths > RT_STATIC_MAX_PATHS)
+        return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_render_region_static: " + std::to_string(units) + " 8x8 pixel blocks x 64 x " +
+                    std::to_string(spp) + " samples = " + std::to_string(paths) + " paths exceed the static work memory (" +
+                    std::to_string(RT_STATIC_MAX_PATHS) + " paths, e.g. a 64x64 tile at 16 samples per pixel)");
+    RT_HIP(hipSetDevice(s->device));
+    unsigned char *base = nullptr;
+    if ((rc = static_scratch_of(s->device, &base))) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    QueueCounters *q_shade = reinterpret_cast<QueueCounters *>(base);
+    QueueCounters *q_finish = reinterpret_cast<QueueCounters *>(base + 256);
+    float *samples = reinterpret_cast<float *>(base + RT_STATIC_SAMPLES_AT);
+    uint32_t *list = reinterpret_cast<uint32_t *>(base + RT_STATIC_LIST_AT);
+    const uint32_t flags = o ? o->flags : 0;
+    const bool detailed = (flags & RT_GPU_FLAG_DETAILED_STATS) != 0;
+    const bool accumulate = (flags & RT_GPU_FLAG_ACCUMULATE) != 0;
+
+    ShadeParams P;
+    memset(&P, 0, sizeof(P));
+    P.S = s->dev;
+    P.S.cam.focal = rt_camera_focal(s->field_of_view, height);
+    P.stats = s->d_stats;
+    P.q = q_shade;
+    P.samples = samples;
+    P.out_list = list; P.out_capacity = RT_STATIC_LIST_SLOTS;
+    P.chunk = RT_SMALL_CHUNK;
+    P.tail_lanes = 32;
+    P.width = width; P.height = height;
+    P.x0 = region.point.x; P.y0 = region.point.y; P.w = region.size.x; P.h = region.size.y;
+    P.blocks_x = G.blocks_x; P.block_rows = G.block_rows;
+    P.band_blocks = G.band_blocks; P.band_rank = G.band_rank; P.band_count = G.band_count;
+    P.first_sample = 0; P.launch_spp = spp;
+    P.sample_offset = o ? o->sample_offset : 0;
+    P.seed0 = (uint32_t)seed; P.seed1 = (uint32_t)(seed >> 32);
+    P.max_segments = (o && o->max_segments) ? (int)o->max_segments : 64;
+    P.half_w = (float)width / 2.0f; P.half_h = (float)height / 2.0f;
+
+    /* one wave per portion of new work at most, never more than 128 waves: the list has a 64-slot chunk of slack for each */
+    const uint64_t portions = units * ((spp + RT_PORTION_SPP - 1) / RT_PORTION_SPP);
+    uint32_t shade_grid = (uint32_t)((portions + 3) / 4);
+    if (shade_grid > 32u) shade_grid = 32u;
+    if (shade_grid > s->shade_blocks) shade_grid = s->shade_blocks;
+
+    RT_HIP(hipMemsetAsync(base, 0, 512, stream));
+    launch_shade(true, detailed, s->specular, shade_grid, stream, P);
+    RT_HIP(hipGetLastError());
+
+    FinishParams F;
+    memset(&F, 0, sizeof(F));
+    F.S = P.S; F.list = list; F.slots = RT_STATIC_LIST_SLOTS; F.slots_reserved = &q_shade->out_reserved;
+    F.samples = samples; F.stats = s->d_stats; F.q = q_finish;
+    F.seed0 = P.seed0; F.seed1 = P.seed1; F.max_segments = P.max_segments; F.half_w = P.half_w; F.half_h = P.half_h;
+    uint32_t fgrid = (uint32_t)((paths + 8192u + 255u) / 256u);      /* a workgroup per 256 slots that can hold a record */
+    if (fgrid > s->finish_blocks) fgrid = s->finish_blocks;
+    const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
+    if (detailed) {
+        if (s->specular) hipLaunchKernelGGL((rt_finish_kernel<true, true>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
+        else hipLaunchKernelGGL((rt_finish_kernel<true, false>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
+    } else {
+        if (s->specular) hipLaunchKernelGGL((rt_finish_kernel<false, true>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
+        else hipLaunchKernelGGL((rt_finish_kernel<false, false>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
+    }
+    RT_HIP(hipGetLastError());
+
+    ResolveParams R;
+    memset(&R, 0, sizeof(R));
+    R.samples = samples; R.pixels = device_pixels;
+    R.x0 = P.x0; R.y0 = P.y0; R.w = P.w; R.h = P.h;
+    R.blocks_x = G.blocks_x; R.block_rows = G.block_rows;
+    R.band_blocks = G.band_blocks; R.band_rank = G.band_rank; R.band_count = G.band_count;
+    R.compact = (flags & RT_GPU_FLAG_COMPACT_BANDS) ? 1 : 0;
+    R.out_pitch = R.compact ? region.size.x : width;
+    R.norm = rt_pixel_norm((o && o->spp_total) ? o->spp_total : spp);
+    R.launch_spp = spp;
+    R.start_from_pixels = accumulate ? 1 : 0;
+    R.finish = accumulate ? 0 : 1;
+    hipLaunchKernelGGL(rt_resolve_kernel, dim3((uint32_t)((units * 64 + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, stream, R);
+    RT_HIP(hipGetLastError());
+    s->launches++;
+    s->samples += (uint64_t)spp * own_rows * region.size.x;
     return RT_GPU_OK;
 }
 

@@ -20,7 +20,7 @@ FLAG_COMPACT_BANDS = 4
 
 EXPORTS = [
     "rt_gpu_device_count", "rt_gpu_last_error", "rt_gpu_scene_create", "rt_gpu_scene_destroy",
-    "rt_gpu_scene_set_camera", "rt_gpu_render_region", "rt_gpu_render_region_device",
+    "rt_gpu_scene_set_camera", "rt_gpu_render_region", "rt_gpu_render_region_device", "rt_gpu_render_region_static",
     "rt_gpu_normalize_device", "rt_gpu_render_jobs", "rt_gpu_find_ray_hit", "rt_gpu_find_ray_hit_serial", "rt_gpu_quantize", "rt_gpu_quantize_device",
     "rt_gpu_get_stats", "rt_gpu_reset_stats", "rt_gpu_eval_math",
 ]
@@ -81,6 +81,7 @@ def lib():
                                            C.c_uint64, C.POINTER(Options)]
         L.rt_gpu_render_region_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, T.Rect2u,
                                                   C.c_uint32, C.c_uint64, C.POINTER(Options), C.c_void_p]
+        L.rt_gpu_render_region_static.argtypes = L.rt_gpu_render_region_device.argtypes
         L.rt_gpu_normalize_device.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
         L.rt_gpu_render_jobs.argtypes = [C.c_void_p, C.POINTER(T.Job), C.c_uint32, C.POINTER(Options)]
         L.rt_gpu_find_ray_hit.argtypes = [C.c_void_p, C.POINTER(T.Ray), C.c_uint32, C.c_float,
@@ -133,6 +134,12 @@ class GpuScene:
     def render_region_device(self, device_ptr, width, height, region, spp, seed, options=None, stream=0):
         """rt_gpu_render_region_device: asynchronous render into device memory."""
         _check(lib().rt_gpu_render_region_device(self._h, device_ptr, width, height, rect(*region), spp, seed,
+                                                 C.byref(options) if options is not None else None,
+                                                 C.c_void_p(stream)))
+
+    def render_region_static(self, device_ptr, width, height, region, spp, seed, options=None, stream=0):
+        """rt_gpu_render_region_static: the same render out of the library's static work memory (no allocation)."""
+        _check(lib().rt_gpu_render_region_static(self._h, device_ptr, width, height, rect(*region), spp, seed,
                                                  C.byref(options) if options is not None else None,
                                                  C.c_void_p(stream)))
 
