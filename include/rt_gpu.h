@@ -53,7 +53,8 @@ typedef struct rt_gpu_scene rt_gpu_scene;      /* opaque: the scene flattened an
 enum {
     RT_GPU_FLAG_DETAILED_STATS = 1u << 0,  /* count node pops, triangle tests, ... (slower) */
     RT_GPU_FLAG_ACCUMULATE     = 1u << 1,  /* pixels hold running UN-normalised sums: read, add, store */
-    RT_GPU_FLAG_COMPACT_BANDS  = 1u << 2   /* device output holds only this rank's bands, packed */
+    RT_GPU_FLAG_COMPACT_BANDS  = 1u << 2,  /* device output holds only this rank's bands, packed */
+    RT_GPU_FLAG_KERNEL_TIMES   = 1u << 3   /* time every launch with HIP events on its stream (rt_gpu_stats.*_ms; implied by DETAILED_STATS) */
 };
 
 /* Optional knobs; pass NULL for the host program's behaviour.  Zero-fill, then
@@ -71,7 +72,10 @@ typedef struct rt_gpu_options {
                               * samples sample_offset + k*spp ... + spp - 1 of every pixel and is stored frame_stride
                               * floats after frame k-1: the same pictures as `frames` calls with those sample offsets,
                               * from launches `frames` times as large (small regions fill the GPU better that way) */
-    uint32_t reserved;
+    uint32_t lane;           /* device render only: which of the handle's work-memory lanes (own stream, own lists) the
+                              * call starts on, < RT_GPU_STREAMS.  Calls of one handle on different lanes, each ordered on
+                              * its own hip_stream, overlap on the GPU: two or three frames in flight from one host
+                              * thread.  0 = the first lane */
     uint64_t frame_stride;   /* floats between the first pixels of consecutive frames; 0 = the size of one frame's
                               * output (width*height*3, or this rank's packed bands) */
 } rt_gpu_options;
@@ -86,12 +90,14 @@ typedef struct rt_gpu_stats {
     uint64_t shade_lanes, pop_lanes, tri_lanes;  /* ... and the lanes that took part in them (of 64 each) */
     uint64_t tree_entries;                       /* (ray, instance) pairs whose tree was entered          */
                              /* all but the first line only with RT_GPU_FLAG_DETAILED_STATS */
-    double   kernel_ms;      /* device time of the shade, tree and finish kernels (HIP events on their stream) */
+    double   kernel_ms;      /* device time of the shade, tree and finish kernels (HIP events on their stream; calls made
+                              * with RT_GPU_FLAG_KERNEL_TIMES or DETAILED_STATS only) */
     double   shade_ms, tree_ms;  /* ... and each kernel's share */
     double   fresh_ms;           /* part of shade_ms spent in the launches that start new paths (first of each batch) */
     double   finish_ms;          /* rt_finish_kernel (last paths of a batch), not part of shade_ms or tree_ms */
-    uint64_t rounds;         /* shade launches (each followed by a tree launch, the last by nothing or by the finish launch) */
-    uint64_t overflowed;     /* paths that found the parked list full (always 0: such a call fails) */
+    uint64_t rounds;         /* shade launches that had work, summed over batches (the first of a batch included) */
+    uint64_t overflowed;     /* paths that found the parked list full (the lists hold every path of a batch, so 0;
+                              * if not, rt_gpu_get_stats fails) */
     uint32_t launches;       /* render calls x sample batches */
     uint32_t reserved;
 } rt_gpu_stats;
@@ -128,13 +134,18 @@ int rt_gpu_render_region(rt_gpu_scene *scene, rt_image3f *image, rt_rect2u regio
                          uint32_t spp, uint64_t seed, const rt_gpu_options *options);
 
 /* The same render into DEVICE memory (width*height float RGB triples, or the
- * packed bands of this rank with RT_GPU_FLAG_COMPACT_BANDS), on `hip_stream` (a
- * hipStream_t; NULL = the default stream).  A frame is a sequence of launches
- * whose number depends on the scene, with a 20-byte read-back after each round:
- * the call returns once the last round has been read back; the final per-pixel
- * sum may still be running on the stream, so work that consumes the pixels goes
- * on the same stream (or synchronises with it).  The buffer belongs to the
- * caller (e.g. a tensor that a collective will gather). */
+ * packed bands of this rank with RT_GPU_FLAG_COMPACT_BANDS), ordered on `hip_stream`
+ * (a hipStream_t; NULL = the default stream): the render starts after the work
+ * already on that stream and the stream goes on after the render's last kernel.
+ * The call is asynchronous: it enqueues a fixed sequence of launches (the number of
+ * rounds a frame needs is decided on the device; launches with nothing to do
+ * return at once) and reads nothing back.  The samples of a call are rendered in
+ * batches that go round-robin over a few streams of the library's own
+ * (RT_GPU_STREAMS, default 3; RT_GPU_BATCH_PATHS paths per batch, default 16 Mi), so
+ * the latency-bound end of one batch overlaps the start of the next; the
+ * picture does not depend on the batching.  Work that consumes the pixels goes
+ * on `hip_stream` (or synchronises with it).  The buffer belongs to the caller
+ * (e.g. a tensor that a collective will gather). */
 int rt_gpu_render_region_device(rt_gpu_scene *scene, float *device_pixels, uint32_t width, uint32_t height,
                                 rt_rect2u region, uint32_t spp, uint64_t seed,
                                 const rt_gpu_options *options, void *hip_stream);
@@ -197,6 +208,10 @@ int rt_gpu_quantize(const float *pixels, size_t pixel_count, uint8_t *rgb);
 
 /* Statistics ---------------------------------------------------------------- */
 int rt_gpu_get_stats(rt_gpu_scene *scene, rt_gpu_stats *out);
+/* The same counters split by the kind of launch that did the work: out[0] the launches that start
+ * new paths, out[1] the launches that resume parked paths, out[2] the tree launches, out[3] the
+ * finishing launches; kernel_ms of each is that kind's device time. */
+int rt_gpu_get_stats_by_kernel(rt_gpu_scene *scene, rt_gpu_stats out[4]);
 int rt_gpu_reset_stats(rt_gpu_scene *scene);
 
 /* Self-test hook: evaluates the device's sin/cos/log/divide/sqrt building

@@ -95,23 +95,32 @@ __device__ __forceinline__ void flush_counters(const rt::Counters &cn, uint64_t 
 #endif
 #define RT_CHUNK 256u                /* parked-list slots a wave reserves per atomic */
 
-struct QueueCounters {               /* device words, zeroed per launch where noted */
-    uint32_t unit_next;              /* fresh: next 8x8 pixel block */
-    uint32_t in_next;                /* resume / tree: next slot of the input list */
-    uint32_t out_reserved;           /* shade: slots reserved in the output list */
-    uint32_t overflow;               /* shade: paths that found the output list full (the call fails) */
-    uint32_t parked;                 /* shade: records actually parked (out_reserved counts whole chunks) */
+/* One record per round of a batch, in device memory, all zeroed by one memset before the batch's first
+ * launch.  Round r's shade launch fills out_reserved / parked / overflow of record r; the tree launch
+ * and the resumed-path launch of round r+1 (or the finishing launch) read them there and advance their
+ * own cursors in the same record, so no launch needs a value from the host: the host enqueues a fixed
+ * sequence of launches and the ones with nothing to do return at once. */
+struct QueueCounters {
+    uint32_t unit_next;              /* new paths: next portion of fresh work */
+    uint32_t in_next;                /* cursor of whoever carries this round's records on (resumed-path or finishing launch) */
+    uint32_t out_reserved;           /* slots reserved in this round's output list */
+    uint32_t overflow;               /* paths that found the output list full (cannot happen: the lists hold every path) */
+    uint32_t parked;                 /* records actually parked (out_reserved counts whole chunks) */
+    uint32_t tree_next;              /* cursor of the tree launch that answers this round's records */
+    uint32_t pad[2];
 };
 
 struct ShadeParams {
     rt_dev_scene S;
     float   *samples;                /* [sample of this launch][unit][pixel of the 8x8 block] RGB */
     uint64_t *stats;
-    QueueCounters *q;
+    QueueCounters *q;                /* this round's record */
+    QueueCounters *q_in;             /* resume: the previous round's record (its list is the input) */
     const uint32_t *in_list;         /* resume: records parked by the previous round (answered) */
     uint32_t *out_list;              /* records this launch parks */
-    uint32_t in_slots, out_capacity;
-    uint32_t chunk;                  /* output slots a wave reserves per atomic (<= RT_CHUNK, multiple of 64) */
+    uint32_t out_capacity;           /* slots of either list */
+    uint32_t finish_below;           /* resume: the round runs only if more records than this were parked (else the finishing launch takes them) */
+    uint32_t chunk;                  /* new paths: output slots a wave reserves per atomic (<= RT_CHUNK, multiple of 64) */
     uint32_t tail_lanes;             /* a wave left with fewer paths than this and no input hands them to the next round (0: never) */
     uint32_t width, height;          /* image */
     uint32_t x0, y0, w, h;           /* region */
@@ -167,6 +176,19 @@ template <bool FRESH, bool STATS, bool SPECULAR>
 __global__ void __launch_bounds__(RT_BLOCK) RT_SHADE_ATTR
 rt_shade_kernel(const ShadeParams P)
 {
+    /* Resumed paths: what there is to do stands in the previous round's record.  Few records: the
+     * finishing launch takes them (this launch returns); otherwise as many workgroups as there are
+     * 256-slot portions of the list work, the others return. */
+    uint32_t in_slots = 0, chunk = P.chunk;
+    if (!FRESH) {
+        const uint32_t reserved = __builtin_amdgcn_readfirstlane(P.q_in->out_reserved);
+        const uint32_t records = __builtin_amdgcn_readfirstlane(P.q_in->parked);
+        if (records <= P.finish_below) return;
+        in_slots = reserved < P.out_capacity ? reserved : P.out_capacity;
+        if (blockIdx.x >= (in_slots + 255u) / 256u) return;
+        /* few records per wave: reserve output slots in smaller chunks (less padding for the next launch to skip) */
+        chunk = records >= (4u << 20) ? RT_CHUNK : RT_SMALL_CHUNK;
+    }
     rt::Stack stk; stk.base = nullptr; stk.stride = 0;                      /* this kernel walks no tree */
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
     const uint32_t lane = threadIdx.x & 63;
@@ -202,10 +224,10 @@ rt_shade_kernel(const ShadeParams P)
         const unsigned long long empty = ~(ready | flight) & RT_SLOT_MASK;
         if (in_cur >= in_end && !cursor_done) {
             uint32_t v = 0;
-            if (lane == 0) v = atomicAdd(&P.q->in_next, RT_IN_BATCH);
+            if (lane == 0) v = atomicAdd(&P.q_in->in_next, RT_IN_BATCH);
             in_cur = __builtin_amdgcn_readfirstlane(v);
-            if (in_cur >= P.in_slots) { cursor_done = true; in_end = in_cur; }
-            else in_end = in_cur + RT_IN_BATCH < P.in_slots ? in_cur + RT_IN_BATCH : P.in_slots;
+            if (in_cur >= in_slots) { cursor_done = true; in_end = in_cur; }
+            else in_end = in_cur + RT_IN_BATCH < in_slots ? in_cur + RT_IN_BATCH : in_slots;
         }
         const uint32_t room = (uint32_t)__popcll(empty);
         const uint32_t n = in_end - in_cur < room ? in_end - in_cur : room;
@@ -248,7 +270,7 @@ rt_shade_kernel(const ShadeParams P)
         uint32_t next_base = 0;
         if (count > room) {                              /* reserve the next chunk; the old one is filled to its end */
             uint32_t v = 0;
-            if (lane == 0) v = atomicAdd(&P.q->out_reserved, P.chunk);
+            if (lane == 0) v = atomicAdd(&P.q->out_reserved, chunk);
             next_base = __builtin_amdgcn_readfirstlane(v);
         }
         if (want) {
@@ -259,7 +281,7 @@ rt_shade_kernel(const ShadeParams P)
                 atomicAdd(&P.q->overflow, 1u);
             }
         }
-        if (count > room) { out_cur = next_base + (count - room); out_end = next_base + P.chunk; }
+        if (count > room) { out_cur = next_base + (count - room); out_end = next_base + chunk; }
         else out_cur += count;
         parked_here += count;
     };
@@ -452,8 +474,10 @@ rt_shade_kernel(const ShadeParams P)
 struct TreeParams {
     rt_dev_scene S;
     uint32_t *list;                  /* parked records: word 0..15 read, 8..14 written back */
-    uint32_t slots;
-    QueueCounters *q;
+    uint32_t capacity;               /* slots of the list */
+    uint32_t fixed_slots;            /* not 0: answer exactly this many slots (closest-hit probes); 0: what the round's record says */
+    uint32_t finish_below;           /* the round's records are left to the finishing launch unless there are more than this */
+    QueueCounters *q;                /* the record of the round that parked the list */
     uint64_t *stats;
 };
 
@@ -476,6 +500,13 @@ template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) RT_TREE_ATTR
 rt_tree_kernel(const TreeParams P)
 {
+    uint32_t slots = P.fixed_slots;
+    if (!slots) {
+        const uint32_t reserved = __builtin_amdgcn_readfirstlane(P.q->out_reserved);
+        if (__builtin_amdgcn_readfirstlane(P.q->parked) <= P.finish_below) return;
+        slots = reserved < P.capacity ? reserved : P.capacity;
+    }
+    if (blockIdx.x >= (slots + 255u) / 256u) return;
     extern __shared__ uint32_t lds[];
     rt::Stack stk; stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK;
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
@@ -514,10 +545,10 @@ rt_tree_kernel(const TreeParams P)
             if (!need) break;
             if (in_cur >= in_end) {
                 uint32_t v = 0;
-                if (lane == 0) v = atomicAdd(&P.q->in_next, RT_TREE_IN_BATCH);
+                if (lane == 0) v = atomicAdd(&P.q->tree_next, RT_TREE_IN_BATCH);
                 in_cur = __builtin_amdgcn_readfirstlane(v);
-                if (in_cur >= P.slots) { input_done = true; break; }
-                in_end = in_cur + RT_TREE_IN_BATCH < P.slots ? in_cur + RT_TREE_IN_BATCH : P.slots;
+                if (in_cur >= slots) { input_done = true; break; }
+                in_end = in_cur + RT_TREE_IN_BATCH < slots ? in_cur + RT_TREE_IN_BATCH : slots;
             }
             const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
             const uint32_t idx = in_cur + rank;
@@ -674,9 +705,13 @@ rt_tree_kernel(const TreeParams P)
  * triangle steps by ballot, trees walked by the lane itself. */
 struct FinishParams {
     rt_dev_scene S;
-    const uint32_t *list; uint32_t slots;
-    const uint32_t *slots_reserved;  /* not NULL: the slots the shade launch reserved, still in device memory (capped by `slots`) */
-    float *samples; uint64_t *stats; QueueCounters *q;
+    const uint32_t *lists[2];        /* round r parked into lists[r & 1] */
+    uint32_t capacity;               /* slots of either list */
+    QueueCounters *rounds;           /* the batch's records, 0 ... last_round */
+    uint32_t last_round;             /* rounds the host enqueued after the first launch */
+    uint32_t finish_below;
+    uint64_t *totals;                /* [0] += shade launches that had work, [1] += paths lost to a full list */
+    float *samples; uint64_t *stats;
     uint32_t seed0, seed1;
     int max_segments;
     float half_w, half_h;
@@ -686,6 +721,23 @@ template <bool STATS, bool SPECULAR>
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_finish_kernel(const FinishParams P)
 {
+    /* The rounds ended with the first one that parked no more than finish_below records (the launches
+     * of the later rounds returned at once), or with the last one enqueued: its records, if any, are
+     * walked to their end here. */
+    uint32_t round = 0, lost = 0;
+    for (;; round++) {
+        lost += __builtin_amdgcn_readfirstlane(P.rounds[round].overflow);
+        if (round == P.last_round || __builtin_amdgcn_readfirstlane(P.rounds[round].parked) <= P.finish_below) break;
+    }
+    QueueCounters *q = P.rounds + round;
+    const uint32_t reserved = __builtin_amdgcn_readfirstlane(q->out_reserved);
+    const uint32_t slots = reserved < P.capacity ? reserved : P.capacity;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.totals) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(P.totals), (unsigned long long)(round + 1u));
+        if (lost) atomicAdd(reinterpret_cast<unsigned long long *>(P.totals + 1), (unsigned long long)lost);
+    }
+    if (__builtin_amdgcn_readfirstlane(q->parked) == 0u || blockIdx.x >= (slots + 255u) / 256u) return;
+    const uint32_t *list = P.lists[round & 1u];
     extern __shared__ uint32_t lds[];
     rt::Stack stk; stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK;
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
@@ -697,11 +749,6 @@ rt_finish_kernel(const FinishParams P)
     uint32_t sample_index = 0;
     uint32_t in_cur = 0, in_end = 0;
     bool input_done = false;
-    uint32_t slots = P.slots;
-    if (P.slots_reserved) {
-        const uint32_t r = __builtin_amdgcn_readfirstlane(*P.slots_reserved);
-        if (r < slots) slots = r;
-    }
     pm.phase = rt::PH_DEAD;
     pm.run(RT_SHADE_WEIGHT,
         [&]() {                                          /* a path ended */
@@ -716,16 +763,16 @@ rt_finish_kernel(const FinishParams P)
                 if (__popcll(need) < 16) break;
                 if (in_cur >= in_end) {
                     uint32_t v = 0;
-                    if (lane == 0) v = atomicAdd(&P.q->in_next, 64u);
+                    if (lane == 0) v = atomicAdd(&q->in_next, 64u);
                     in_cur = __builtin_amdgcn_readfirstlane(v);
                     if (in_cur >= slots) { input_done = true; break; }
                     in_end = in_cur + 64u < slots ? in_cur + 64u : slots;
                 }
                 const uint32_t idx = in_cur + (uint32_t)__popcll(need & lanes_below);
                 if (pm.phase == rt::PH_DEAD && idx < in_end &&
-                    pm.load_record(P.list + (size_t)idx * RT_RECORD_WORDS, sample_index)) {
-                    if (!(P.list[(size_t)idx * RT_RECORD_WORDS] & 0x80u)) {   /* the query still has a tree to walk */
-                        pm.tv.inst = (int)(P.list[(size_t)idx * RT_RECORD_WORDS + 15] & 0xFFFFu);   /* instance the ray was parked for */
+                    pm.load_record(list + (size_t)idx * RT_RECORD_WORDS, sample_index)) {
+                    if (!(list[(size_t)idx * RT_RECORD_WORDS] & 0x80u)) {   /* the query still has a tree to walk */
+                        pm.tv.inst = (int)(list[(size_t)idx * RT_RECORD_WORDS + 15] & 0xFFFFu);   /* instance the ray was parked for */
                         pm.phase = rt::PH_SCAN;
                         if (STATS) cn.root_tests--;      /* counted when the ray was parked */
                     }
@@ -1013,26 +1060,47 @@ static int static_scratch_of(int device, unsigned char **out)
     return 0;
 }
 
+#define RT_KINDS 4                    /* detailed counters are kept per kind of launch: */
+enum { KIND_FRESH = 0, KIND_RESUME = 1, KIND_TREE = 2, KIND_FINISH = 3 };
+#define RT_MAX_LANES 8
+
+/* Work memory of one batch of samples in flight: a frame's batches go round-robin over the lanes,
+ * each on its own stream, so the latency-bound last rounds of one batch run beside the
+ * machine-filling first launch of the next. */
+struct BatchLane {
+    hipStream_t stream = nullptr;
+    float *d_samples = nullptr; uint64_t sample_bytes = 0;     /* per-sample values between shading and the per-pixel sum */
+    uint32_t *d_parked[2] = {nullptr, nullptr}; uint64_t parked_records = 0;   /* paths in transit, ping-pong */
+    QueueCounters *d_rounds = nullptr;                         /* one record per round */
+    hipEvent_t done = nullptr;                                 /* after the lane's latest per-pixel sum */
+};
+
+struct Knobs {                        /* environment, read once per scene handle */
+    uint64_t scratch_mb = 4096, parked_mb = 98304;
+    uint32_t lanes = 3, max_rounds = 16, tail_lanes = 32;
+    uint64_t batch_paths = 80u << 20;
+    int64_t finish_below = -1;         /* < 0: by the size of the batch */
+    bool trace_rounds = false;
+};
+
 struct rt_gpu_scene {
     int device = 0;
     rt_dev_scene dev;
     float field_of_view = 0.0f;
     std::vector<void *> allocations;
-    uint64_t *d_stats = nullptr;
+    uint64_t *d_stats = nullptr;      /* RT_KINDS x RT_STAT_WORDS counters, then [rounds that had work, paths lost] */
     uint32_t *d_aes_table = nullptr;
     float *d_frame = nullptr; size_t frame_floats = 0;
-    float *d_samples = nullptr; uint64_t scratch_bytes = 0;   /* per-sample values between shading and resolve */
-    uint32_t *d_parked[2] = {nullptr, nullptr}; uint64_t parked_records = 0;   /* paths in transit, ping-pong */
-    QueueCounters *d_queue = nullptr;
+    QueueCounters *d_queue = nullptr; /* closest-hit probes */
+    BatchLane lanes[RT_MAX_LANES];
+    hipEvent_t ev_start = nullptr;
+    Knobs knobs;
     uint32_t shade_blocks = 0, resume_blocks = 0, tree_blocks = 0, finish_blocks = 0;   /* persistent grid sizes */
     bool specular = true;                                     /* some material is a mirror or glass */
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> tree_timers;
-    double tree_ms = 0.0, fresh_ms = 0.0, finish_ms = 0.0;
-    uint64_t overflowed = 0, rounds = 0;
-    struct Timer { hipEvent_t first, second; int kind; };      /* 0 resumed paths, 1 new paths, 2 finish */
+    struct Timer { hipEvent_t first, second; int kind; };
     std::vector<Timer> timers;                                /* pending kernel timings */
     std::vector<hipEvent_t> spare_events;
-    double kernel_ms = 0.0;
+    double kind_ms[RT_KINDS] = {0.0, 0.0, 0.0, 0.0};
     uint32_t launches = 0;
     uint64_t samples = 0;
 };
@@ -1101,6 +1169,14 @@ int rt_gpu_device_count(void)
 
 const char *rt_gpu_last_error(void) { return g_error.c_str(); }
 
+static void free_lane(BatchLane &L)
+{
+    if (L.d_samples) (void)hipFree(L.d_samples);
+    for (int k = 0; k < 2; k++) if (L.d_parked[k]) (void)hipFree(L.d_parked[k]);
+    L.d_samples = nullptr; L.sample_bytes = 0;
+    L.d_parked[0] = L.d_parked[1] = nullptr; L.parked_records = 0;
+}
+
 void rt_gpu_scene_destroy(rt_gpu_scene *s)
 {
     if (!s) return;
@@ -1108,12 +1184,42 @@ void rt_gpu_scene_destroy(rt_gpu_scene *s)
     (void)hipDeviceSynchronize();
     for (void *p : s->allocations) (void)hipFree(p);
     if (s->d_frame) (void)hipFree(s->d_frame);
-    if (s->d_samples) (void)hipFree(s->d_samples);
-    for (int k = 0; k < 2; k++) if (s->d_parked[k]) (void)hipFree(s->d_parked[k]);
-    for (auto &t : s->tree_timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
+    for (auto &L : s->lanes) {
+        free_lane(L);
+        if (L.d_rounds) (void)hipFree(L.d_rounds);
+        if (L.done) (void)hipEventDestroy(L.done);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     for (auto &t : s->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     for (auto e : s->spare_events) (void)hipEventDestroy(e);
     delete s;
+}
+
+/* RT_GPU_* environment knobs, validated once when a scene handle is made */
+static int read_knobs(Knobs &k)
+{
+    auto number = [](const char *name, uint64_t lo, uint64_t hi, uint64_t &out) -> int {
+        const char *e = getenv(name);
+        if (!e || !*e) return 0;
+        char *end = nullptr;
+        unsigned long long v = strtoull(e, &end, 10);
+        if (*end || v < lo || v > hi)
+            return fail(RT_GPU_ERR_ARGUMENT, std::string(name) + "=" + e + " is outside " + std::to_string(lo) + " ... " + std::to_string(hi));
+        out = v;
+        return 0;
+    };
+    uint64_t v;
+    int rc = 0;
+    if ((rc = number("RT_GPU_SCRATCH_MB", 1, 1u << 20, k.scratch_mb))) return rc;
+    if ((rc = number("RT_GPU_PARKED_MB", 1, 1u << 20, k.parked_mb))) return rc;
+    v = k.lanes; if ((rc = number("RT_GPU_STREAMS", 1, RT_MAX_LANES, v))) return rc; k.lanes = (uint32_t)v;
+    v = k.max_rounds; if ((rc = number("RT_GPU_MAX_ROUNDS", 0, 255, v))) return rc; k.max_rounds = (uint32_t)v;
+    v = k.tail_lanes; if ((rc = number("RT_GPU_TAIL_LANES", 0, 64, v))) return rc; k.tail_lanes = (uint32_t)v;
+    if ((rc = number("RT_GPU_BATCH_PATHS", 64, 1ull << 40, k.batch_paths))) return rc;
+    v = 0; if (getenv("RT_GPU_FINISH_BELOW")) { if ((rc = number("RT_GPU_FINISH_BELOW", 0, 0xFFFFFFFFull, v))) return rc; k.finish_below = (int64_t)v; }
+    k.trace_rounds = getenv("RT_GPU_TRACE_ROUNDS") != nullptr;
+    return 0;
 }
 
 int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
@@ -1164,7 +1270,8 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
         if ((rc = upload(s, flat.tris, &s->dev.tris))) break;
         if ((rc = upload(s, flat.attrs, &s->dev.attrs))) break;
         if ((rc = upload(s, flat.texels, &s->dev.texels))) break;
-        std::vector<uint64_t> zeros(RT_STAT_WORDS, 0);
+        if ((rc = read_knobs(s->knobs))) break;
+        std::vector<uint64_t> zeros(RT_KINDS * RT_STAT_WORDS + 2, 0);
         const uint64_t *st = nullptr;
         if ((rc = upload(s, zeros, &st))) break;
         s->d_stats = const_cast<uint64_t *>(st);
@@ -1191,6 +1298,16 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
             s->shade_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_shade);
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
         }
+        {   /* one stream, one record table and one event per batch lane; their work memory comes with the first render */
+            bool ok = hipEventCreateWithFlags(&s->ev_start, hipEventDisableTiming) == hipSuccess;
+            for (uint32_t i = 0; ok && i < s->knobs.lanes; i++) {
+                BatchLane &L = s->lanes[i];
+                ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&L.done, hipEventDisableTiming) == hipSuccess &&
+                     hipMalloc(reinterpret_cast<void **>(&L.d_rounds), sizeof(QueueCounters) * (s->knobs.max_rounds + 1)) == hipSuccess;
+            }
+            if (!ok) { rc = fail(RT_GPU_ERR_DEVICE, "could not create the streams, events and round records of the batch lanes"); break; }
+        }
         {   /* this device's address of the static work memory (rt_gpu_render_region_static), asked once per device */
             unsigned char *unused = nullptr;
             if ((rc = static_scratch_of(s->device, &unused))) break;
@@ -1215,26 +1332,18 @@ int rt_gpu_scene_set_camera(rt_gpu_scene *s, const void *camera)
     return RT_GPU_OK;
 }
 
-static int ensure_scratch(rt_gpu_scene *s, uint64_t sample_bytes, uint64_t parked_records)
+/* work memory of one lane: grows, never shrinks; false = the device has no room (everything of the lane freed) */
+static bool ensure_lane(BatchLane &L, uint64_t sample_bytes, uint64_t parked_records)
 {
-    if (s->scratch_bytes < sample_bytes) {
-        if (s->d_samples) { (void)hipDeviceSynchronize(); (void)hipFree(s->d_samples); s->d_samples = nullptr; s->scratch_bytes = 0; }
-        if (hipMalloc(reinterpret_cast<void **>(&s->d_samples), sample_bytes) != hipSuccess)
-            return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the sample scratch (" + std::to_string(sample_bytes >> 20) + " MiB)");
-        s->scratch_bytes = sample_bytes;
-    }
-    if (s->parked_records < parked_records) {
-        (void)hipDeviceSynchronize();
-        for (int k = 0; k < 2; k++) {
-            if (s->d_parked[k]) { (void)hipFree(s->d_parked[k]); s->d_parked[k] = nullptr; }
-            if (hipMalloc(reinterpret_cast<void **>(&s->d_parked[k]), parked_records * RT_RECORD_WORDS * 4) != hipSuccess) {
-                s->parked_records = 0;
-                return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the parked-path lists");
-            }
-        }
-        s->parked_records = parked_records;
-    }
-    return 0;
+    if (L.sample_bytes >= sample_bytes && L.parked_records >= parked_records) return true;
+    (void)hipStreamSynchronize(L.stream);
+    free_lane(L);
+    bool ok = hipMalloc(reinterpret_cast<void **>(&L.d_samples), sample_bytes) == hipSuccess;
+    for (int k = 0; ok && k < 2; k++)
+        ok = hipMalloc(reinterpret_cast<void **>(&L.d_parked[k]), parked_records * RT_RECORD_WORDS * 4) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); free_lane(L); return false; }
+    L.sample_bytes = sample_bytes; L.parked_records = parked_records;
+    return true;
 }
 
 static hipEvent_t take_event(rt_gpu_scene *s)
@@ -1249,23 +1358,31 @@ static void settle_timers(rt_gpu_scene *s)
 {
     for (auto &t : s->timers) {
         float ms = 0.0f;
-        if (hipEventSynchronize(t.second) == hipSuccess && hipEventElapsedTime(&ms, t.first, t.second) == hipSuccess) {
-            if (t.kind == 2) s->finish_ms += ms;
-            else s->kernel_ms += ms;
-            if (t.kind == 1) s->fresh_ms += ms;
-        }
+        if (hipEventSynchronize(t.second) == hipSuccess && hipEventElapsedTime(&ms, t.first, t.second) == hipSuccess)
+            s->kind_ms[t.kind] += ms;
         s->spare_events.push_back(t.first);
         s->spare_events.push_back(t.second);
     }
     s->timers.clear();
-    for (auto &t : s->tree_timers) {
-        float ms = 0.0f;
-        if (hipEventSynchronize(t.second) == hipSuccess && hipEventElapsedTime(&ms, t.first, t.second) == hipSuccess)
-            s->tree_ms += ms;
-        s->spare_events.push_back(t.first);
-        s->spare_events.push_back(t.second);
+}
+
+/* a launch with, if asked for, a pair of events around it on its stream (its duration lands in kind_ms[kind]) */
+extern "C++" template <class Launch>
+static int timed_launch(rt_gpu_scene *s, bool timed, int kind, hipStream_t stream, Launch &&launch)
+{
+    hipEvent_t e0 = timed ? take_event(s) : nullptr, e1 = timed ? take_event(s) : nullptr;
+    if (timed && !(e0 && e1)) {                          /* no events to be had: run untimed */
+        if (e0) s->spare_events.push_back(e0);
+        if (e1) s->spare_events.push_back(e1);
+        e0 = e1 = nullptr;
     }
-    s->tree_timers.clear();
+    bool recorded = e0 && hipEventRecord(e0, stream) == hipSuccess;
+    launch();
+    hipError_t err = hipGetLastError();
+    if (recorded && err == hipSuccess && hipEventRecord(e1, stream) == hipSuccess) s->timers.push_back({e0, e1, kind});
+    else if (e0) { s->spare_events.push_back(e0); s->spare_events.push_back(e1); }
+    if (err != hipSuccess) return fail(RT_GPU_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(err));
+    return 0;
 }
 
 /* which 8-row block rows of the region this launch walks; *own_rows = pixel rows among them */
@@ -1297,6 +1414,17 @@ static int launch_geometry(const rt_gpu_options *o, rt_rect2u region, RenderPara
     return 0;
 }
 
+static void launch_finish(bool detailed, bool specular, uint32_t grid, size_t lds, hipStream_t stream, const FinishParams &F)
+{
+    if (detailed) {
+        if (specular) hipLaunchKernelGGL((rt_finish_kernel<true, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, F);
+        else hipLaunchKernelGGL((rt_finish_kernel<true, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, F);
+    } else {
+        if (specular) hipLaunchKernelGGL((rt_finish_kernel<false, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, F);
+        else hipLaunchKernelGGL((rt_finish_kernel<false, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, F);
+    }
+}
+
 int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t width, uint32_t height,
                                 rt_rect2u region, uint32_t spp, uint64_t seed,
                                 const rt_gpu_options *o, void *hip_stream)
@@ -1307,8 +1435,9 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     if ((uint64_t)region.point.x + region.size.x > width || (uint64_t)region.point.y + region.size.y > height)
         return fail(RT_GPU_ERR_ARGUMENT, "region exceeds the image");
     if ((uint64_t)width * height > 0xFFFFFFFFull) return fail(RT_GPU_ERR_ARGUMENT, "image too large for 32-bit pixel indices");
+    if (o && o->max_segments >= (1u << 24)) return fail(RT_GPU_ERR_ARGUMENT, "max_segments must be below 2^24");
     RT_HIP(hipSetDevice(s->device));
-    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    hipStream_t caller = static_cast<hipStream_t>(hip_stream);
 
     RenderParams G;
     memset(&G, 0, sizeof(G));
@@ -1317,8 +1446,10 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     if (rc) return rc;
     if (G.block_rows == 0) return RT_GPU_OK;
     if (width > 0xFFFFu || height > 0xFFFFu) return fail(RT_GPU_ERR_ARGUMENT, "image sides above 65535 are not supported");
+    const Knobs &K = s->knobs;
     const uint32_t flags = o ? o->flags : 0;
     const bool detailed = (flags & RT_GPU_FLAG_DETAILED_STATS) != 0;
+    const bool timed = detailed || (flags & RT_GPU_FLAG_KERNEL_TIMES) != 0;
     const bool accumulate = (flags & RT_GPU_FLAG_ACCUMULATE) != 0;
     const uint32_t frames = (o && o->frames > 1) ? o->frames : 1;
     if ((uint64_t)spp * frames + (o ? o->sample_offset : 0) > 0xFFFFFFFFull) return fail(RT_GPU_ERR_ARGUMENT, "sample indices exceed 32 bits");
@@ -1327,13 +1458,13 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     const uint64_t frame_stride = (o && o->frame_stride) ? o->frame_stride : frame_floats;
     if (frames > 1 && frame_stride < frame_floats) return fail(RT_GPU_ERR_ARGUMENT, "frame_stride is smaller than a frame");
     const uint64_t total_spp = (uint64_t)spp * frames;
+    if (o && o->lane >= K.lanes) return fail(RT_GPU_ERR_ARGUMENT, "options.lane must be below RT_GPU_STREAMS (" + std::to_string(K.lanes) + ")");
+    const uint32_t first_lane = o ? o->lane : 0;
 
     ShadeParams P;
     memset(&P, 0, sizeof(P));
     P.S = s->dev;
     P.S.cam.focal = rt_camera_focal(s->field_of_view, height);
-    P.stats = s->d_stats;
-    P.q = s->d_queue;
     P.width = width; P.height = height;
     P.x0 = region.point.x; P.y0 = region.point.y; P.w = region.size.x; P.h = region.size.y;
     P.blocks_x = G.blocks_x; P.block_rows = G.block_rows;
@@ -1353,156 +1484,135 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     R.out_pitch = R.compact ? region.size.x : width;
     R.norm = rt_pixel_norm((o && o->spp_total) ? o->spp_total : spp);
 
-    /* how many samples per pixel one launch carries: bounded by the sample scratch (12 bytes per
-     * item) and by the two parked lists (192 bytes per record each).  A list has room for every
-     * path of the launch at once plus one partly used chunk per wave, so parking never fails. */
+    /* The call's samples are rendered in batches (whole samples per pixel of the region; whole frames when
+     * the call makes several).  A batch needs 12 bytes per path for the sample values and two lists
+     * of 192 bytes per path (+ one partly used chunk per wave): every path of the batch can be parked
+     * at once, so parking cannot fail.  Batches go round-robin over the lanes: the budgets are shared
+     * between the lanes in use. */
     const uint64_t units = (uint64_t)G.blocks_x * G.block_rows;
     const uint64_t items_per_sample = units * 64;
-    /* no more workgroups than there are portions of fresh work for their waves (small regions) */
-    const uint64_t portions_max = units * ((spp + RT_PORTION_SPP - 1) / RT_PORTION_SPP);
-    uint32_t shade_grid = s->shade_blocks;
-    if ((portions_max + 3) / 4 < shade_grid) shade_grid = (uint32_t)((portions_max + 3) / 4);
-    const uint64_t chunk_slack = (uint64_t)shade_grid * (RT_BLOCK / 64) * RT_CHUNK;
-    uint64_t scratch_mb = 4096, parked_mb = 32768;
-    if (const char *e = getenv("RT_GPU_SCRATCH_MB")) scratch_mb = (uint64_t)atoll(e);
-    if (const char *e = getenv("RT_GPU_PARKED_MB")) parked_mb = (uint64_t)atoll(e);
-    uint64_t per_launch = (scratch_mb << 20) / (items_per_sample * 12);
-    const uint64_t list_records = ((parked_mb << 20) / 2) / (RT_RECORD_WORDS * 4);
-    if (list_records < items_per_sample + chunk_slack)
-        return fail(RT_GPU_ERR_MEMORY, "RT_GPU_PARKED_MB is too small for one sample per pixel of this region");
-    if (per_launch > (list_records - chunk_slack) / items_per_sample) per_launch = (list_records - chunk_slack) / items_per_sample;
-    if (per_launch > total_spp) per_launch = total_spp;
-    if (per_launch * items_per_sample > 0xFFFFFF00ull / 3) per_launch = (0xFFFFFF00ull / 3) / items_per_sample;
-    if (per_launch < 1) return fail(RT_GPU_ERR_ARGUMENT, "region too large for one launch");
-    if (frames > 1) {
-        if (per_launch < spp) {
-            /* not even one frame fits a launch: the frames one after the other, each in its sample batches */
-            rt_gpu_options one = *o;
-            one.frames = 1; one.frame_stride = 0;
-            for (uint32_t k = 0; k < frames; k++) {
-                one.sample_offset = o->sample_offset + k * spp;
-                rc = rt_gpu_render_region_device(s, device_pixels + (size_t)k * frame_stride, width, height, region, spp, seed, &one, hip_stream);
-                if (rc) return rc;
+    uint64_t batch_spp = (K.batch_paths + items_per_sample / 2) / items_per_sample;
+    if (batch_spp < 1) batch_spp = 1;
+    if (batch_spp > total_spp) batch_spp = total_spp;
+    if (batch_spp * items_per_sample > 0xFFFFFF00ull / 3) batch_spp = (0xFFFFFF00ull / 3) / items_per_sample;
+    if (batch_spp < 1) return fail(RT_GPU_ERR_ARGUMENT, "region too large for one launch");
+    size_t free_bytes = 0, device_bytes = 0;
+    if (hipMemGetInfo(&free_bytes, &device_bytes) != hipSuccess) { (void)hipGetLastError(); free_bytes = ~(size_t)0; }
+    uint64_t held = 0;
+    for (uint32_t i = 0; i < K.lanes; i++) held += s->lanes[i].sample_bytes + 2 * s->lanes[i].parked_records * RT_RECORD_WORDS * 4;
+    uint32_t shade_grid = 0, lanes_used = 0, lane_cap = K.lanes;
+    uint64_t batches = 0, capacity = 0, chunk_slack = 0;
+    (void)device_bytes;
+    for (;;) {
+        if (frames > 1) {
+            if (batch_spp < spp) {
+                /* not even one frame fits a batch: the frames one after the other, each in its sample batches */
+                rt_gpu_options one = *o;
+                one.frames = 1; one.frame_stride = 0;
+                for (uint32_t k = 0; k < frames; k++) {
+                    one.sample_offset = o->sample_offset + k * spp;
+                    rc = rt_gpu_render_region_device(s, device_pixels + (size_t)k * frame_stride, width, height, region, spp, seed, &one, hip_stream);
+                    if (rc) return rc;
+                }
+                return RT_GPU_OK;
             }
-            return RT_GPU_OK;
+            batch_spp -= batch_spp % spp;                /* whole frames per batch */
+            batches = (total_spp + batch_spp - 1) / batch_spp;
+        } else {
+            batches = (total_spp + batch_spp - 1) / batch_spp;
+            batch_spp = (total_spp + batches - 1) / batches;        /* batches of equal size */
         }
-        per_launch -= per_launch % spp;                  /* whole frames per launch */
+        lanes_used = (uint32_t)(batches < lane_cap ? batches : lane_cap);
+        /* no more workgroups than there are portions of fresh work for their waves (small regions) */
+        const uint64_t portions_max = units * ((batch_spp + RT_PORTION_SPP - 1) / RT_PORTION_SPP);
+        shade_grid = s->shade_blocks;
+        if ((portions_max + 3) / 4 < shade_grid) shade_grid = (uint32_t)((portions_max + 3) / 4);
+        /* every wave of a launch leaves at most one reserved chunk partly used; the resumed-path launches get
+         * no more workgroups than the first launch */
+        chunk_slack = (uint64_t)shade_grid * (RT_BLOCK / 64) * RT_CHUNK;
+        capacity = (batch_spp * items_per_sample + chunk_slack + RT_CHUNK - 1) / RT_CHUNK * RT_CHUNK;
+        const uint64_t sample_bytes = batch_spp * items_per_sample * 12, list_bytes = capacity * RT_RECORD_WORDS * 4;
+        /* the budgets are the handle's: a lane gets its share whether or not the other lanes are in use */
+        const bool fits_budget = sample_bytes * lane_cap <= (K.scratch_mb << 20) && 2 * list_bytes * lane_cap <= (K.parked_mb << 20) &&
+                                 capacity <= 0xFFFFFF00ull;
+        /* what the lanes already hold is freed before they grow, so it counts as available */
+        const bool fits_device = free_bytes == ~(size_t)0 ||
+                                 (double)((sample_bytes + 2 * list_bytes) * lanes_used) <= 0.9 * ((double)free_bytes + (double)held);
+        bool ok = fits_budget && fits_device;
+        for (uint32_t i = 0; ok && i < lanes_used; i++) ok = ensure_lane(s->lanes[(first_lane + i) % K.lanes], sample_bytes, capacity);
+        if (ok) break;
+        if (batch_spp == 1 || (frames > 1 && batch_spp == spp)) {
+            if (lane_cap > 1) { lane_cap--; continue; }              /* the smallest batches: fewer of them in flight */
+            if (frames > 1) { batch_spp = spp - 1; continue; }       /* fall back to one frame after the other */
+            if (!fits_budget)
+                return fail(RT_GPU_ERR_MEMORY, "RT_GPU_SCRATCH_MB / RT_GPU_PARKED_MB are too small for one sample per pixel of this region (" +
+                            std::to_string((sample_bytes * lane_cap) >> 20) + " + " + std::to_string((2 * list_bytes * lane_cap) >> 20) + " MiB needed)");
+            return fail(RT_GPU_ERR_MEMORY, "the device has no room for the work memory of one sample per pixel of this region (" +
+                        std::to_string(((sample_bytes + 2 * list_bytes) * lanes_used) >> 20) + " MiB)");
+        }
+        batch_spp = frames > 1 ? (batch_spp / spp + 1) / 2 * spp : (batch_spp + 1) / 2;      /* smaller batches and try again */
     }
-    uint64_t capacity = per_launch * items_per_sample + chunk_slack;
-    capacity = (capacity + RT_CHUNK - 1) / RT_CHUNK * RT_CHUNK;
-    if (capacity > 0xFFFFFF00ull) return fail(RT_GPU_ERR_ARGUMENT, "region too large for one launch");
-    rc = ensure_scratch(s, per_launch * items_per_sample * 12, capacity);
-    if (rc) return rc;
-    P.samples = s->d_samples; R.samples = s->d_samples;
-    P.out_capacity = (uint32_t)capacity;
 
     const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
-    const uint32_t tree_grid = s->tree_blocks;
     const uint32_t resolve_grid = (uint32_t)((units * 64 + RT_BLOCK - 1) / RT_BLOCK);
-
-    const bool trace_rounds = getenv("RT_GPU_TRACE_ROUNDS") != nullptr;
-    /* parked records at or below which one launch finishes the paths: 1/128 of the launch's paths, within
-     * [65536, 262144] (the finishing launch runs few lanes per wave, so a small launch must not leave it much) */
-    uint64_t finish_paths = per_launch * items_per_sample / 128;
+    /* parked records at or below which one launch finishes the paths: 1/128 of the batch's paths, within
+     * [65536, 262144] (the finishing launch runs few lanes per wave, so a small batch must not leave it much) */
+    uint64_t finish_paths = batch_spp * items_per_sample / 128;
     if (finish_paths < 65536) finish_paths = 65536;
     if (finish_paths > 262144) finish_paths = 262144;
-    uint32_t finish_below = (uint32_t)finish_paths;
-    if (const char *e = getenv("RT_GPU_FINISH_BELOW")) finish_below = (uint32_t)atoll(e);
+    const uint32_t finish_below = K.finish_below >= 0 ? (uint32_t)K.finish_below : (uint32_t)finish_paths;
     /* a wave that has no input left and fewer paths than this hands them to the next round; needs the
-     * finishing launch to end the frame (without it the rounds run to the last path themselves) */
-    P.tail_lanes = 32;
-    if (const char *e = getenv("RT_GPU_TAIL_LANES")) P.tail_lanes = (uint32_t)atoll(e);
-    if (P.tail_lanes > 64) P.tail_lanes = 64;
-    if (finish_below == 0) P.tail_lanes = 0;
-    auto trace_t = std::chrono::steady_clock::now();
-    uint64_t trace_w[RT_STAT_WORDS] = {0};
-    if (trace_rounds && detailed) (void)hipMemcpy(trace_w, s->d_stats, sizeof(trace_w), hipMemcpyDeviceToHost);
-    for (uint64_t first64 = 0; first64 < total_spp; first64 += per_launch) {
+     * finishing launch to end the batch (without it the rounds run to the last path themselves) */
+    P.tail_lanes = finish_below == 0 ? 0 : K.tail_lanes;
+    P.finish_below = finish_below;
+    P.out_capacity = (uint32_t)capacity;
+    const uint32_t rounds = K.max_rounds;
+    const uint32_t resume_grid = s->resume_blocks < shade_grid ? s->resume_blocks : shade_grid;
+
+    RT_HIP(hipEventRecord(s->ev_start, caller));
+    hipEvent_t previous_sum = nullptr;                   /* per-pixel sums run in batch order: a pixel's samples are added in sample order */
+    for (uint64_t batch = 0, first64 = 0; first64 < total_spp; batch++, first64 += batch_spp) {
+        BatchLane &L = s->lanes[(first_lane + batch) % K.lanes];
+        hipStream_t stream = L.stream;
+        if (batch < lanes_used) RT_HIP(hipStreamWaitEvent(stream, s->ev_start, 0));
         const uint32_t first = (uint32_t)first64;
         P.first_sample = first;
-        P.launch_spp = (uint32_t)(total_spp - first64 < per_launch ? total_spp - first64 : per_launch);
-        uint32_t *list_in = s->d_parked[0], *list_out = s->d_parked[1];
-        uint32_t in_slots = 0, in_records = 0;
-        for (uint32_t round = 0;; round++) {
-            RT_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(QueueCounters), stream));
-            P.in_list = list_in; P.in_slots = in_slots; P.out_list = list_out;
-            /* few records per wave: reserve output slots in smaller chunks (less padding to skip later)
-             * and launch no more workgroups than there are 64-record portions of input */
-            P.chunk = (round == 0 || in_records >= (4u << 20)) ? RT_CHUNK : RT_SMALL_CHUNK;
-            uint32_t grid = shade_grid;
-            if (round > 0) {
-                if (s->resume_blocks < grid) grid = s->resume_blocks;
-                if ((in_slots + 255) / 256 < grid) grid = (in_slots + 255) / 256;
-            }
-            hipEvent_t e0 = take_event(s), e1 = take_event(s);
-            if (e0 && e1) RT_HIP(hipEventRecord(e0, stream));
-            launch_shade(round == 0, detailed, s->specular, grid, stream, P);
-            RT_HIP(hipGetLastError());
-            if (e0 && e1) { RT_HIP(hipEventRecord(e1, stream)); s->timers.push_back({e0, e1, round == 0 ? 1 : 0}); }
-            QueueCounters qc;
-            RT_HIP(hipMemcpyAsync(&qc, s->d_queue, sizeof(qc), hipMemcpyDeviceToHost, stream));
-            RT_HIP(hipStreamSynchronize(stream));
-            s->overflowed += qc.overflow;
-            s->rounds++;
-            if (qc.overflow) return fail(RT_GPU_ERR_DEVICE, "parked-path list overflow (" + std::to_string(qc.overflow) + " paths lost)");
-            uint32_t parked = qc.out_reserved < capacity ? qc.out_reserved : (uint32_t)capacity;
-            if (trace_rounds) {
-                const auto now = std::chrono::steady_clock::now();
-                float shade_ms = 0.0f, tree_ms = 0.0f;
-                if (!s->timers.empty()) (void)hipEventElapsedTime(&shade_ms, s->timers.back().first, s->timers.back().second);
-                if (round > 0 && !s->tree_timers.empty()) (void)hipEventElapsedTime(&tree_ms, s->tree_timers.back().first, s->tree_timers.back().second);
-                fprintf(stderr, "round %u: in %u records (%u slots) -> parked %u records (%u slots); tree %.3f ms, shade %.3f ms, host %.3f ms since the previous read-back\n",
-                        round, in_records, in_slots, qc.parked, parked, tree_ms, shade_ms, std::chrono::duration<double, std::milli>(now - trace_t).count());
-                if (detailed) {                          /* step counters of this round's launches */
-                    uint64_t w[RT_STAT_WORDS];
-                    if (hipMemcpy(w, s->d_stats, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess) {
-                        fprintf(stderr, "         shade steps %llu (%.1f lanes), node steps %llu (%.1f lanes), leaf steps %llu (%.1f lanes)\n",
-                                (unsigned long long)(w[13] - trace_w[13]), (double)(w[16] - trace_w[16]) / (double)(w[13] - trace_w[13] + 1),
-                                (unsigned long long)(w[14] - trace_w[14]), (double)(w[17] - trace_w[17]) / (double)(w[14] - trace_w[14] + 1),
-                                (unsigned long long)(w[15] - trace_w[15]), (double)(w[18] - trace_w[18]) / (double)(w[15] - trace_w[15] + 1));
-                        memcpy(trace_w, w, sizeof(w));
-                    }
-                }
-                trace_t = now;
-            }
-            if (parked == 0) break;
-            RT_HIP(hipMemsetAsync(s->d_queue, 0, sizeof(QueueCounters), stream));
-            if (qc.parked <= finish_below) {
-                /* a handful of paths left: one launch walks them to their end */
-                FinishParams F;
-                memset(&F, 0, sizeof(F));
-                F.S = P.S; F.list = list_out; F.slots = parked; F.samples = P.samples; F.stats = s->d_stats; F.q = s->d_queue;
-                F.seed0 = P.seed0; F.seed1 = P.seed1; F.max_segments = P.max_segments; F.half_w = P.half_w; F.half_h = P.half_h;
-                uint32_t fgrid = (parked + 255) / 256;
-                if (fgrid > s->finish_blocks) fgrid = s->finish_blocks;
-                hipEvent_t f0 = take_event(s), f1 = take_event(s);
-                if (f0 && f1) RT_HIP(hipEventRecord(f0, stream));
-                if (detailed) {
-                    if (s->specular) hipLaunchKernelGGL((rt_finish_kernel<true, true>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
-                    else hipLaunchKernelGGL((rt_finish_kernel<true, false>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
-                } else {
-                    if (s->specular) hipLaunchKernelGGL((rt_finish_kernel<false, true>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
-                    else hipLaunchKernelGGL((rt_finish_kernel<false, false>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
-                }
-                RT_HIP(hipGetLastError());
-                if (f0 && f1) { RT_HIP(hipEventRecord(f1, stream)); s->timers.push_back({f0, f1, 2}); }
-                break;
-            }
-            /* answer the parked queries, then resume those paths */
+        P.launch_spp = (uint32_t)(total_spp - first64 < batch_spp ? total_spp - first64 : batch_spp);
+        P.samples = L.d_samples;
+        RT_HIP(hipMemsetAsync(L.d_rounds, 0, sizeof(QueueCounters) * (rounds + 1), stream));
+        /* round 0: new paths */
+        P.stats = s->d_stats + KIND_FRESH * RT_STAT_WORDS;
+        P.q = L.d_rounds; P.q_in = nullptr; P.in_list = nullptr; P.out_list = L.d_parked[0];
+        P.chunk = RT_CHUNK;
+        if ((rc = timed_launch(s, timed, KIND_FRESH, stream, [&]() { launch_shade(true, detailed, s->specular, shade_grid, stream, P); }))) return rc;
+        /* rounds 1 ...: answer the parked queries, resume those paths.  What a round has to do stands in
+         * the previous round's record; launches of rounds that are not needed return at once. */
+        for (uint32_t r = 1; r <= rounds; r++) {
             TreeParams T;
             memset(&T, 0, sizeof(T));
-            T.S = P.S; T.list = list_out; T.slots = parked; T.q = s->d_queue; T.stats = s->d_stats;
-            uint32_t tgrid = tree_grid;
-            if ((parked + 255) / 256 < tgrid) tgrid = (parked + 255) / 256;
-            hipEvent_t t0 = take_event(s), t1 = take_event(s);
-            if (t0 && t1) RT_HIP(hipEventRecord(t0, stream));
-            if (detailed) hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(tgrid), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, stream, T);
-            else hipLaunchKernelGGL(rt_tree_kernel<false>, dim3(tgrid), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, stream, T);
-            RT_HIP(hipGetLastError());
-            if (t0 && t1) { RT_HIP(hipEventRecord(t1, stream)); s->tree_timers.emplace_back(t0, t1); }
-            uint32_t *tmp = list_in; list_in = list_out; list_out = tmp;
-            in_slots = parked; in_records = qc.parked;
+            T.S = P.S; T.list = L.d_parked[(r - 1) & 1]; T.capacity = P.out_capacity; T.finish_below = finish_below;
+            T.q = L.d_rounds + (r - 1); T.stats = s->d_stats + KIND_TREE * RT_STAT_WORDS;
+            if ((rc = timed_launch(s, timed, KIND_TREE, stream, [&]() {
+                    if (detailed) hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(s->tree_blocks), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, stream, T);
+                    else hipLaunchKernelGGL(rt_tree_kernel<false>, dim3(s->tree_blocks), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, stream, T);
+                }))) return rc;
+            P.stats = s->d_stats + KIND_RESUME * RT_STAT_WORDS;
+            P.q_in = L.d_rounds + (r - 1); P.q = L.d_rounds + r;
+            P.in_list = L.d_parked[(r - 1) & 1]; P.out_list = L.d_parked[r & 1];
+            if ((rc = timed_launch(s, timed, KIND_RESUME, stream, [&]() { launch_shade(false, detailed, s->specular, resume_grid, stream, P); }))) return rc;
         }
+        /* whatever the rounds left parked: one launch walks those paths to their end */
+        FinishParams F;
+        memset(&F, 0, sizeof(F));
+        F.S = P.S; F.lists[0] = L.d_parked[0]; F.lists[1] = L.d_parked[1]; F.capacity = P.out_capacity;
+        F.rounds = L.d_rounds; F.last_round = rounds; F.finish_below = finish_below;
+        F.totals = s->d_stats + RT_KINDS * RT_STAT_WORDS;
+        F.samples = P.samples; F.stats = s->d_stats + KIND_FINISH * RT_STAT_WORDS;
+        F.seed0 = P.seed0; F.seed1 = P.seed1; F.max_segments = P.max_segments; F.half_w = P.half_w; F.half_h = P.half_h;
+        if ((rc = timed_launch(s, timed, KIND_FINISH, stream, [&]() { launch_finish(detailed, s->specular, s->finish_blocks, lds, stream, F); }))) return rc;
+
+        if (previous_sum) RT_HIP(hipStreamWaitEvent(stream, previous_sum, 0));
+        R.samples = L.d_samples;
         if (frames == 1) {
             R.launch_spp = P.launch_spp;
             R.start_from_pixels = (accumulate || first > 0) ? 1 : 0;
@@ -1510,21 +1620,36 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
             hipLaunchKernelGGL(rt_resolve_kernel, dim3(resolve_grid), dim3(RT_BLOCK), 0, stream, R);
             RT_HIP(hipGetLastError());
         } else {
-            /* the launch holds whole frames: frame j of it owns samples j*spp ... of the scratch */
+            /* the batch holds whole frames: frame j of it owns samples j*spp ... of the batch */
             for (uint32_t j = 0; j < P.launch_spp / spp; j++) {
-                ResolveParams F = R;
-                F.samples = P.samples + 3 * (size_t)j * spp * items_per_sample;
-                F.pixels = device_pixels + (size_t)(first / spp + j) * frame_stride;
-                F.launch_spp = spp;
-                F.start_from_pixels = accumulate ? 1 : 0;
-                F.finish = accumulate ? 0 : 1;
-                hipLaunchKernelGGL(rt_resolve_kernel, dim3(resolve_grid), dim3(RT_BLOCK), 0, stream, F);
+                ResolveParams F2 = R;
+                F2.samples = L.d_samples + 3 * (size_t)j * spp * items_per_sample;
+                F2.pixels = device_pixels + (size_t)(first / spp + j) * frame_stride;
+                F2.launch_spp = spp;
+                F2.start_from_pixels = accumulate ? 1 : 0;
+                F2.finish = accumulate ? 0 : 1;
+                hipLaunchKernelGGL(rt_resolve_kernel, dim3(resolve_grid), dim3(RT_BLOCK), 0, stream, F2);
                 RT_HIP(hipGetLastError());
             }
         }
+        RT_HIP(hipEventRecord(L.done, stream));
+        previous_sum = L.done;
         s->launches++;
+        if (K.trace_rounds) {                            /* debugging aid: wait for the batch and print its rounds */
+            std::vector<QueueCounters> q(rounds + 1);
+            RT_HIP(hipStreamSynchronize(stream));
+            RT_HIP(hipMemcpy(q.data(), L.d_rounds, sizeof(QueueCounters) * (rounds + 1), hipMemcpyDeviceToHost));
+            for (uint32_t r = 0; r <= rounds; r++) {
+                fprintf(stderr, "batch %llu round %u: parked %u records in %u slots%s\n", (unsigned long long)batch, r, q[r].parked, q[r].out_reserved,
+                        q[r].parked <= finish_below ? " -> finishing launch" : "");
+                if (q[r].parked <= finish_below) break;
+            }
+        }
     }
-    if (s->timers.size() + s->tree_timers.size() > 4096) settle_timers(s);
+    /* the caller's stream goes on when every lane has made its last per-pixel sum */
+    const uint64_t batches_made = (total_spp + batch_spp - 1) / batch_spp;
+    for (uint32_t i = 0; i < lanes_used && i < batches_made; i++) RT_HIP(hipStreamWaitEvent(caller, s->lanes[(first_lane + i) % K.lanes].done, 0));
+    if (s->timers.size() > 8192) settle_timers(s);
     s->samples += total_spp * own_rows * region.size.x;
     return RT_GPU_OK;
 }
@@ -1562,8 +1687,7 @@ int rt_gpu_render_region_static(rt_gpu_scene *s, float *device_pixels, uint32_t 
     unsigned char *base = nullptr;
     if ((rc = static_scratch_of(s->device, &base))) return rc;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    QueueCounters *q_shade = reinterpret_cast<QueueCounters *>(base);
-    QueueCounters *q_finish = reinterpret_cast<QueueCounters *>(base + 256);
+    QueueCounters *q_shade = reinterpret_cast<QueueCounters *>(base);        /* the one round of this launch sequence */
     float *samples = reinterpret_cast<float *>(base + RT_STATIC_SAMPLES_AT);
     uint32_t *list = reinterpret_cast<uint32_t *>(base + RT_STATIC_LIST_AT);
     const uint32_t flags = o ? o->flags : 0;
@@ -1574,7 +1698,7 @@ int rt_gpu_render_region_static(rt_gpu_scene *s, float *device_pixels, uint32_t 
     memset(&P, 0, sizeof(P));
     P.S = s->dev;
     P.S.cam.focal = rt_camera_focal(s->field_of_view, height);
-    P.stats = s->d_stats;
+    P.stats = s->d_stats + KIND_FRESH * RT_STAT_WORDS;
     P.q = q_shade;
     P.samples = samples;
     P.out_list = list; P.out_capacity = RT_STATIC_LIST_SLOTS;
@@ -1602,19 +1726,15 @@ int rt_gpu_render_region_static(rt_gpu_scene *s, float *device_pixels, uint32_t 
 
     FinishParams F;
     memset(&F, 0, sizeof(F));
-    F.S = P.S; F.list = list; F.slots = RT_STATIC_LIST_SLOTS; F.slots_reserved = &q_shade->out_reserved;
-    F.samples = samples; F.stats = s->d_stats; F.q = q_finish;
+    F.S = P.S; F.lists[0] = list; F.lists[1] = list; F.capacity = RT_STATIC_LIST_SLOTS;
+    F.rounds = q_shade; F.last_round = 0; F.finish_below = 0xFFFFFFFFu;      /* every parked path is finished here */
+    F.totals = s->d_stats + RT_KINDS * RT_STAT_WORDS;
+    F.samples = samples; F.stats = s->d_stats + KIND_FINISH * RT_STAT_WORDS;
     F.seed0 = P.seed0; F.seed1 = P.seed1; F.max_segments = P.max_segments; F.half_w = P.half_w; F.half_h = P.half_h;
     uint32_t fgrid = (uint32_t)((paths + 8192u + 255u) / 256u);      /* a workgroup per 256 slots that can hold a record */
     if (fgrid > s->finish_blocks) fgrid = s->finish_blocks;
     const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
-    if (detailed) {
-        if (s->specular) hipLaunchKernelGGL((rt_finish_kernel<true, true>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
-        else hipLaunchKernelGGL((rt_finish_kernel<true, false>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
-    } else {
-        if (s->specular) hipLaunchKernelGGL((rt_finish_kernel<false, true>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
-        else hipLaunchKernelGGL((rt_finish_kernel<false, false>), dim3(fgrid), dim3(RT_BLOCK), lds, stream, F);
-    }
+    launch_finish(detailed, s->specular, fgrid, lds, stream, F);
     RT_HIP(hipGetLastError());
 
     ResolveParams R;
@@ -1753,7 +1873,7 @@ int rt_gpu_render_jobs(rt_gpu_scene *s, const rt_job *jobs, uint32_t job_count, 
     else
         hipLaunchKernelGGL(rt_render_jobs_kernel<false>, dim3(grid), dim3(RT_BLOCK), lds, nullptr, P);
     e = hipGetLastError();
-    if (e0 && e1) { (void)hipEventRecord(e1, nullptr); s->timers.push_back({e0, e1, 0}); }
+    if (e0 && e1) { (void)hipEventRecord(e1, nullptr); s->timers.push_back({e0, e1, KIND_FRESH}); }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(d_jobs);
     if (e != hipSuccess) return fail(RT_GPU_ERR_DEVICE, std::string("job kernel: ") + hipGetErrorString(e));
@@ -1802,7 +1922,7 @@ static int find_ray_hit(rt_gpu_scene *s, const rt_ray *rays, uint32_t ray_count,
         if (e == hipSuccess) {
             TreeParams T;
             memset(&T, 0, sizeof(T));
-            T.S = s->dev; T.list = d_list; T.slots = ray_count; T.q = s->d_queue; T.stats = s->d_stats;
+            T.S = s->dev; T.list = d_list; T.capacity = ray_count; T.fixed_slots = ray_count; T.q = s->d_queue; T.stats = s->d_stats;
             uint32_t tgrid = s->tree_blocks < grid ? s->tree_blocks : grid;
             hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(tgrid), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, nullptr, T);
             e = hipGetLastError();
@@ -1845,25 +1965,61 @@ int rt_gpu_quantize(const float *pixels, size_t pixel_count, uint8_t *rgb)
     return RT_GPU_OK;
 }
 
-int rt_gpu_get_stats(rt_gpu_scene *s, rt_gpu_stats *out)
+static void fill_counters(rt_gpu_stats *out, const uint64_t *w)
 {
-    if (!s || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_get_stats: NULL argument");
-    RT_HIP(hipSetDevice(s->device));
-    RT_HIP(hipDeviceSynchronize());
-    settle_timers(s);
-    uint64_t w[RT_STAT_WORDS];
-    RT_HIP(hipMemcpy(w, s->d_stats, sizeof(w), hipMemcpyDeviceToHost));
-    memset(out, 0, sizeof(*out));
-    out->samples = w[0] ? w[0] : s->samples;
-    out->rays = w[1]; out->shadow_rays = w[2]; out->root_tests = w[3]; out->interior_pops = w[4];
+    out->samples = w[0]; out->rays = w[1]; out->shadow_rays = w[2]; out->root_tests = w[3]; out->interior_pops = w[4];
     out->leaf_pops = w[5]; out->tri_tests = w[6]; out->tri_hits = w[7]; out->tex_lookups = w[8];
     out->rng_draws = w[9]; out->light_tests = w[10]; out->sphere_tests = w[11]; out->plane_tests = w[12];
     out->shade_steps = w[13]; out->pop_steps = w[14]; out->tri_steps = w[15];
     out->shade_lanes = w[16]; out->pop_lanes = w[17]; out->tri_lanes = w[18]; out->tree_entries = w[19];
-    out->kernel_ms = s->kernel_ms + s->tree_ms + s->finish_ms;
-    out->shade_ms = s->kernel_ms; out->tree_ms = s->tree_ms; out->fresh_ms = s->fresh_ms; out->finish_ms = s->finish_ms;
-    out->rounds = s->rounds; out->overflowed = s->overflowed;
+}
+
+static int read_stats(rt_gpu_scene *s, uint64_t w[RT_KINDS * RT_STAT_WORDS + 2])
+{
+    RT_HIP(hipSetDevice(s->device));
+    RT_HIP(hipDeviceSynchronize());
+    settle_timers(s);
+    RT_HIP(hipMemcpy(w, s->d_stats, sizeof(uint64_t) * (RT_KINDS * RT_STAT_WORDS + 2), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rt_gpu_get_stats(rt_gpu_scene *s, rt_gpu_stats *out)
+{
+    if (!s || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_get_stats: NULL argument");
+    uint64_t w[RT_KINDS * RT_STAT_WORDS + 2];
+    int rc = read_stats(s, w);
+    if (rc) return rc;
+    uint64_t sum[RT_STAT_WORDS] = {0};
+    for (int k = 0; k < RT_KINDS; k++) for (int i = 0; i < RT_STAT_WORDS; i++) sum[i] += w[k * RT_STAT_WORDS + i];
+    memset(out, 0, sizeof(*out));
+    fill_counters(out, sum);
+    if (!out->samples) out->samples = s->samples;
+    out->kernel_ms = s->kind_ms[KIND_FRESH] + s->kind_ms[KIND_RESUME] + s->kind_ms[KIND_TREE] + s->kind_ms[KIND_FINISH];
+    out->shade_ms = s->kind_ms[KIND_FRESH] + s->kind_ms[KIND_RESUME]; out->tree_ms = s->kind_ms[KIND_TREE];
+    out->fresh_ms = s->kind_ms[KIND_FRESH]; out->finish_ms = s->kind_ms[KIND_FINISH];
+    out->rounds = w[RT_KINDS * RT_STAT_WORDS]; out->overflowed = w[RT_KINDS * RT_STAT_WORDS + 1];
     out->launches = s->launches;
+    if (out->overflowed) return fail(RT_GPU_ERR_DEVICE, "parked-path list overflow (" + std::to_string(out->overflowed) + " paths lost): the frames since the last reset are incomplete");
+    return RT_GPU_OK;
+}
+
+int rt_gpu_get_stats_by_kernel(rt_gpu_scene *s, rt_gpu_stats out[4])
+{
+    if (!s || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_get_stats_by_kernel: NULL argument");
+    uint64_t w[RT_KINDS * RT_STAT_WORDS + 2];
+    int rc = read_stats(s, w);
+    if (rc) return rc;
+    memset(out, 0, sizeof(rt_gpu_stats) * RT_KINDS);
+    for (int k = 0; k < RT_KINDS; k++) {
+        fill_counters(out + k, w + k * RT_STAT_WORDS);
+        out[k].kernel_ms = s->kind_ms[k];
+        out[k].launches = s->launches;
+    }
+    out[KIND_FRESH].shade_ms = out[KIND_FRESH].fresh_ms = s->kind_ms[KIND_FRESH];
+    out[KIND_RESUME].shade_ms = s->kind_ms[KIND_RESUME];
+    out[KIND_TREE].tree_ms = s->kind_ms[KIND_TREE];
+    out[KIND_FINISH].finish_ms = s->kind_ms[KIND_FINISH];
+    out[KIND_FINISH].rounds = w[RT_KINDS * RT_STAT_WORDS]; out[KIND_FINISH].overflowed = w[RT_KINDS * RT_STAT_WORDS + 1];
     return RT_GPU_OK;
 }
 
@@ -1873,8 +2029,9 @@ int rt_gpu_reset_stats(rt_gpu_scene *s)
     RT_HIP(hipSetDevice(s->device));
     RT_HIP(hipDeviceSynchronize());
     settle_timers(s);
-    RT_HIP(hipMemset(s->d_stats, 0, sizeof(uint64_t) * RT_STAT_WORDS));
-    s->kernel_ms = 0.0; s->tree_ms = 0.0; s->fresh_ms = 0.0; s->finish_ms = 0.0; s->launches = 0; s->samples = 0; s->rounds = 0; s->overflowed = 0;
+    RT_HIP(hipMemset(s->d_stats, 0, sizeof(uint64_t) * (RT_KINDS * RT_STAT_WORDS + 2)));
+    for (int k = 0; k < RT_KINDS; k++) s->kind_ms[k] = 0.0;
+    s->launches = 0; s->samples = 0;
     return RT_GPU_OK;
 }
 

@@ -17,19 +17,21 @@ LIB_PATH = os.environ.get("RT_GPU_LIB", os.path.join(_HERE, "librt_gpu.so"))   #
 FLAG_DETAILED_STATS = 1
 FLAG_ACCUMULATE = 2
 FLAG_COMPACT_BANDS = 4
+FLAG_KERNEL_TIMES = 8
+KERNEL_KINDS = ("new_paths", "resumed_paths", "tree", "finish")
 
 EXPORTS = [
     "rt_gpu_device_count", "rt_gpu_last_error", "rt_gpu_scene_create", "rt_gpu_scene_destroy",
     "rt_gpu_scene_set_camera", "rt_gpu_render_region", "rt_gpu_render_region_device", "rt_gpu_render_region_static",
     "rt_gpu_normalize_device", "rt_gpu_render_jobs", "rt_gpu_find_ray_hit", "rt_gpu_find_ray_hit_serial", "rt_gpu_quantize", "rt_gpu_quantize_device",
-    "rt_gpu_get_stats", "rt_gpu_reset_stats", "rt_gpu_eval_math",
+    "rt_gpu_get_stats", "rt_gpu_get_stats_by_kernel", "rt_gpu_reset_stats", "rt_gpu_eval_math",
 ]
 
 
 class Options(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "struct_size", "max_segments", "sample_offset", "spp_total", "flags",
-        "band_rows", "band_rank", "band_count", "frames", "reserved")] + [("frame_stride", C.c_uint64)]
+        "band_rows", "band_rank", "band_count", "frames", "lane")] + [("frame_stride", C.c_uint64)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -90,6 +92,7 @@ def lib():
         L.rt_gpu_quantize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.rt_gpu_quantize_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rt_gpu_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.rt_gpu_get_stats_by_kernel.argtypes = [C.c_void_p, C.POINTER(Stats * 4)]
         L.rt_gpu_reset_stats.argtypes = [C.c_void_p]
         L.rt_gpu_eval_math.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
         _LIB = L
@@ -162,6 +165,12 @@ class GpuScene:
         st = Stats()
         _check(lib().rt_gpu_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def stats_by_kernel(self):
+        """{kind: counters} for the four kinds of launch (KERNEL_KINDS)."""
+        st = (Stats * 4)()
+        _check(lib().rt_gpu_get_stats_by_kernel(self._h, C.byref(st)))
+        return {name: st[i].as_dict() for i, name in enumerate(KERNEL_KINDS)}
 
     def reset_stats(self):
         _check(lib().rt_gpu_reset_stats(self._h))

@@ -304,45 +304,44 @@ def test_several_frames_in_one_call(gpu_scenes, monkeypatch):
     """options.frames = 3: frame k is made of samples sample_offset + k*spp ... of every pixel and lands
     frame_stride floats after frame k-1: each equals the oracle's frame with that sample offset, in
     the plain layout, in the packed bands of a rank, and when the sample scratch is too small for a
-    whole frame per launch (the frames then run one after the other)."""
+    whole frame per batch (the frames then run one after the other).  The memory knobs are read when
+    a scene handle is made."""
     import torch
     from raytracing_amd import multi_gpu
     sh, gs = gpu_scenes("dog_room")
     W, H, spp, seed, frames = 48, 32, 3, 19, 3
     want = [oracle_counter(sh, W, H, (0, 0, W, H), spp, seed, sample_offset=5 + k * spp) for k in range(frames)]
-    for env in ({}, {"RT_GPU_SCRATCH_MB": "0"}):
-        monkeypatch.delenv("RT_GPU_SCRATCH_MB", raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        if env:       # 0 MB would refuse to render at all: give it room for two samples of the region
-            monkeypatch.setenv("RT_GPU_SCRATCH_MB", "1")
-            big_w, big_h = 256, 192                     # 49152 pixels x 12 B x 3 spp > 1 MB
-            want_big = [oracle_counter(sh, big_w, big_h, (0, 0, big_w, big_h), spp, seed, sample_offset=k * spp) for k in range(2)]
-            buf = torch.zeros((2, big_h, big_w, 3), dtype=torch.float32, device="cuda")
-            gs.render_region_device(buf.data_ptr(), big_w, big_h, (0, 0, big_w, big_h), spp, seed, gpu.Options(frames=2))
-            torch.cuda.synchronize()
-            for k in range(2):
-                assert L.same_bits(buf[k].cpu().numpy(), want_big[k]).all(), k
-            continue
-        pad = 7 * 3                                     # frames need not be contiguous
-        buf = torch.full((frames * (H * W * 3 + pad),), -1.0, dtype=torch.float32, device="cuda")
-        gs.render_region_device(buf.data_ptr(), W, H, (0, 0, W, H), spp, seed,
-                                gpu.Options(frames=frames, sample_offset=5, frame_stride=H * W * 3 + pad))
-        torch.cuda.synchronize()
-        got = buf.cpu().numpy().reshape(frames, H * W * 3 + pad)
-        for k in range(frames):
-            assert L.same_bits(got[k, :H * W * 3].reshape(H, W, 3), want[k]).all(), k
-            assert (got[k, H * W * 3:] == -1.0).all()
-        world, rank = 2, 1
-        rows = multi_gpu.packed_rows(world, H)
-        mine = torch.zeros((frames, rows, W, 3), dtype=torch.float32, device="cuda")
-        gs.render_region_device(mine.data_ptr(), W, H, (0, 0, W, H), spp, seed,
-                                gpu.Options(frames=frames, sample_offset=5, band_rows=8, band_rank=rank, band_count=world,
-                                            flags=gpu.FLAG_COMPACT_BANDS))
-        torch.cuda.synchronize()
-        own = multi_gpu.rows_of_rank(rank, world, H)
-        for k in range(frames):
-            assert L.same_bits(mine[k, :len(own)].cpu().numpy(), want[k][own]).all(), k
+    # room for two samples of the region only: 49152 pixels x 12 B x 3 spp > 1 MB
+    monkeypatch.setenv("RT_GPU_SCRATCH_MB", "1")
+    small = gpu.GpuScene(sh)
+    monkeypatch.delenv("RT_GPU_SCRATCH_MB")
+    big_w, big_h = 256, 192
+    want_big = [oracle_counter(sh, big_w, big_h, (0, 0, big_w, big_h), spp, seed, sample_offset=k * spp) for k in range(2)]
+    buf = torch.zeros((2, big_h, big_w, 3), dtype=torch.float32, device="cuda")
+    small.render_region_device(buf.data_ptr(), big_w, big_h, (0, 0, big_w, big_h), spp, seed, gpu.Options(frames=2))
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert L.same_bits(buf[k].cpu().numpy(), want_big[k]).all(), k
+    small.close()
+    pad = 7 * 3                                     # frames need not be contiguous
+    buf = torch.full((frames * (H * W * 3 + pad),), -1.0, dtype=torch.float32, device="cuda")
+    gs.render_region_device(buf.data_ptr(), W, H, (0, 0, W, H), spp, seed,
+                            gpu.Options(frames=frames, sample_offset=5, frame_stride=H * W * 3 + pad))
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy().reshape(frames, H * W * 3 + pad)
+    for k in range(frames):
+        assert L.same_bits(got[k, :H * W * 3].reshape(H, W, 3), want[k]).all(), k
+        assert (got[k, H * W * 3:] == -1.0).all()
+    world, rank = 2, 1
+    rows = multi_gpu.packed_rows(world, H)
+    mine = torch.zeros((frames, rows, W, 3), dtype=torch.float32, device="cuda")
+    gs.render_region_device(mine.data_ptr(), W, H, (0, 0, W, H), spp, seed,
+                            gpu.Options(frames=frames, sample_offset=5, band_rows=8, band_rank=rank, band_count=world,
+                                        flags=gpu.FLAG_COMPACT_BANDS))
+    torch.cuda.synchronize()
+    own = multi_gpu.rows_of_rank(rank, world, H)
+    for k in range(frames):
+        assert L.same_bits(mine[k, :len(own)].cpu().numpy(), want[k][own]).all(), k
     img, arr = host.new_image(W, H)
     with pytest.raises(RuntimeError, match="device-buffer"):
         gs.render_region(img, (0, 0, W, H), spp, seed, gpu.Options(frames=2))
@@ -366,34 +365,52 @@ def test_progressive_frame_with_a_checkpoint_in_the_middle(gpu_scenes, tmp_path)
 
 
 def test_memory_budgets_and_round_policies_do_not_change_the_picture(gpu_scenes, monkeypatch):
-    """How a frame is cut into launches is an implementation matter: a small sample scratch (several
-    sample batches per call), a parked-list budget that forces batches, rounds to the very end
-    (no finishing launch), a finishing launch right after the first one, and waves that hand their
-    last paths to the next round early, late or never must all give the oracle's bits; a parked-list
-    budget too small for one sample per pixel is an error."""
-    sh, gs = gpu_scenes("three_dogs")
+    """How a frame is cut into batches, streams and rounds is an implementation matter: a small sample
+    scratch (several batches per call), a parked-list budget that forces batches, tiny batches over
+    one, two or eight streams, rounds to the very end (no finishing launch), no rounds at all (the
+    finishing launch right after the first one), one or two rounds then the finishing launch with
+    most paths still under way, and waves that hand their last paths to the next round early, late
+    or never must all give the oracle's bits; budgets too small for one sample per pixel are an
+    error, and so is a knob outside its range.  (The knobs are read when a scene handle is made.)"""
+    sh, _ = gpu_scenes("three_dogs")
     W = H = 96
     want = oracle_counter(sh, W, H, (0, 0, W, H), 12, 5)
-    cases = [{}, {"RT_GPU_SCRATCH_MB": "1"}, {"RT_GPU_PARKED_MB": "421"}, {"RT_GPU_FINISH_BELOW": "0"},
+    knobs = ("RT_GPU_SCRATCH_MB", "RT_GPU_PARKED_MB", "RT_GPU_FINISH_BELOW", "RT_GPU_TAIL_LANES", "RT_GPU_STREAMS",
+             "RT_GPU_BATCH_PATHS", "RT_GPU_MAX_ROUNDS")
+    cases = [{}, {"RT_GPU_SCRATCH_MB": "1"}, {"RT_GPU_PARKED_MB": "64"}, {"RT_GPU_FINISH_BELOW": "0"},
              {"RT_GPU_FINISH_BELOW": "4000000000"}, {"RT_GPU_SCRATCH_MB": "1", "RT_GPU_FINISH_BELOW": "0"},
              {"RT_GPU_TAIL_LANES": "0"}, {"RT_GPU_TAIL_LANES": "64", "RT_GPU_FINISH_BELOW": "100"},
-             {"RT_GPU_TAIL_LANES": "8", "RT_GPU_FINISH_BELOW": "1"}]
+             {"RT_GPU_TAIL_LANES": "8", "RT_GPU_FINISH_BELOW": "1"},
+             {"RT_GPU_STREAMS": "1", "RT_GPU_BATCH_PATHS": "20000"}, {"RT_GPU_STREAMS": "2", "RT_GPU_BATCH_PATHS": "30000"},
+             {"RT_GPU_STREAMS": "8", "RT_GPU_BATCH_PATHS": "9216"},
+             {"RT_GPU_MAX_ROUNDS": "0", "RT_GPU_FINISH_BELOW": "0"}, {"RT_GPU_MAX_ROUNDS": "1", "RT_GPU_FINISH_BELOW": "10"},
+             {"RT_GPU_MAX_ROUNDS": "2", "RT_GPU_FINISH_BELOW": "0", "RT_GPU_BATCH_PATHS": "40000"}]
     for env in cases:
-        for k in ("RT_GPU_SCRATCH_MB", "RT_GPU_PARKED_MB", "RT_GPU_FINISH_BELOW", "RT_GPU_TAIL_LANES"):
+        for k in knobs:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
+        gs = gpu.GpuScene(sh)
         img, got = host.new_image(W, H)
-        gs.reset_stats()
         gs.render_region(img, (0, 0, W, H), 12, 5)
         assert L.same_bits(got, want).all(), env
         st = gs.stats()
-        if env.get("RT_GPU_SCRATCH_MB") == "1":
+        if env.get("RT_GPU_SCRATCH_MB") == "1" or "RT_GPU_BATCH_PATHS" in env:
             assert st["launches"] > 1, (env, st["launches"])        # the call really was cut into batches
+        assert st["overflowed"] == 0
+        gs.close()
+    for k in knobs:
+        monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("RT_GPU_PARKED_MB", "1")
+    gs = gpu.GpuScene(sh)
     img, got = host.new_image(W, H)
     with pytest.raises(RuntimeError, match="RT_GPU_PARKED_MB"):
         gs.render_region(img, (0, 0, W, H), 2, 5)
+    gs.close()
+    monkeypatch.setenv("RT_GPU_PARKED_MB", "0")
+    with pytest.raises(gpu.GpuError, match="RT_GPU_PARKED_MB=0 is outside"):
+        gpu.GpuScene(sh)
+    monkeypatch.delenv("RT_GPU_PARKED_MB")
 
 
 def test_path_length_cap(gpu_scenes):
