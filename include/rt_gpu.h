@@ -206,6 +206,27 @@ int rt_gpu_find_ray_hit_serial(rt_gpu_scene *scene, const rt_ray *rays, uint32_t
  * float pixels; rgb receives 3 bytes per pixel. */
 int rt_gpu_quantize(const float *pixels, size_t pixel_count, uint8_t *rgb);
 
+/* One frame over several GPUs of a node, from ONE host process -------------------------
+ * Replaces the thread pool of the host program (src/main.c:1056-1074: 15 threads, 64x64 tiles from an
+ * atomic counter) by the node's GPUs: the frame is cut into 8-row bands dealt round-robin to the
+ * devices, every device renders its bands (the scene is resident on each), one RCCL all-gather
+ * over xGMI leaves every device with all bands, device 0 puts them in image order and the frame
+ * lands in image->pixels.  The frame is the single-device frame bit for bit.  RCCL is loaded at
+ * run time (librccl.so) and only when more than one device is used. */
+typedef struct rt_gpu_multi rt_gpu_multi;
+int rt_gpu_multi_create(const rt_scene *scene, int device_count /* 0 = every visible device */, rt_gpu_multi **out);
+void rt_gpu_multi_destroy(rt_gpu_multi *multi);
+int rt_gpu_multi_device_count(const rt_gpu_multi *multi);
+/* Drop-in for the whole render block of main() (src/main.c:1056-1088) for one image. */
+int rt_gpu_multi_render_frame(rt_gpu_multi *multi, rt_image3f *image, uint32_t spp, uint64_t seed,
+                              const rt_gpu_options *options /* max_segments, sample_offset, spp_total; NULL = defaults */);
+/* Rows of a device's packed band buffer (the last band of the image may be short: padding rows). */
+uint32_t rt_gpu_multi_rows_per_rank(uint32_t height, uint32_t band_rows, uint32_t world);
+/* The assembly step alone: `world` packed band buffers one after the other (as the all-gather leaves
+ * them, rt_gpu_multi_rows_per_rank rows each) -> width*height pixels in image order, on device memory. */
+int rt_gpu_assemble_bands_device(const float *device_all, float *device_frame, uint32_t width, uint32_t height,
+                                 uint32_t band_rows, uint32_t world, void *hip_stream);
+
 /* Statistics ---------------------------------------------------------------- */
 int rt_gpu_get_stats(rt_gpu_scene *scene, rt_gpu_stats *out);
 /* The same counters split by the kind of launch that did the work: out[0] the launches that start

@@ -22,12 +22,13 @@ int rt_host_mesh_build_tree(rt_mesh *mesh);
  * src/main.c:183-258): copies the parser's arrays (entry 0 of each is the
  * parser's dummy), applies the axis permutation, splits every polygon into a
  * fan of triangles (a quad gives (0,1,2),(0,2,3) as the reference) and builds
- * the tree.  indices_ptn holds (position, texcoord, normal) index triples. */
+ * the tree.  indices_ptn holds index_count (position, texcoord, normal) index
+ * triples, face after face; -6 if the faces name more corners than that. */
 int rt_host_mesh_from_obj_arrays(const float *positions, uint32_t position_count,
                                  const float *texcoords, uint32_t texcoord_count,
                                  const float *normals, uint32_t normal_count,
-                                 const uint32_t *indices_ptn, const uint32_t *face_vertices,
-                                 uint32_t face_count, rt_mesh *out);
+                                 const uint32_t *indices_ptn, uint64_t index_count,
+                                 const uint32_t *face_vertices, uint32_t face_count, rt_mesh *out);
 
 void rt_host_mesh_free(rt_mesh *mesh);
 

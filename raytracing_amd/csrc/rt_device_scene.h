@@ -56,7 +56,8 @@ struct rt_dev_mesh {                     /* one per distinct host Mesh */
     uint32_t node_base;
     uint32_t stack_need;                 /* deepest level + 2 */
     uint32_t tame_boxes;                 /* 1: every box coordinate is 0 or has magnitude in [2^-40, 2^40] */
-    uint32_t pad[3];
+    uint32_t node_count;                 /* interior node records of this mesh */
+    uint32_t pad[2];
 };
 
 struct rt_dev_instance {                 /* one per Scene_Mesh */
@@ -87,7 +88,7 @@ struct rt_dev_camera {
 
 struct rt_dev_scene {
     rt_dev_camera cam;
-    int32_t light_count, sphere_count, plane_count, instance_count, material_count, texture_count;
+    int32_t light_count, sphere_count, plane_count, instance_count, material_count, texture_count, mesh_count;
     const rt_dev_light    *lights;
     const rt_dev_sphere   *spheres;
     const rt_dev_plane    *planes;

@@ -266,6 +266,7 @@ int rt_flatten_scene(const rt_scene *scene, rt_flat_scene &out)
                 }
                 dm.tame_boxes = ok ? 1u : 0u;
             }
+            dm.node_count = (uint32_t)(out.nodes.size() - dm.node_base);
             dm.stack_need = walk.deepest + 2 + (walk.chained ? 2 : 0);
             if (dm.stack_need > out.stack_cap) out.stack_cap = dm.stack_need;
             found = mesh_index.emplace(mesh, (uint32_t)out.meshes.size()).first;

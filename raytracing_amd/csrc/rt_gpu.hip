@@ -485,11 +485,23 @@ struct TreeParams {
 #define RT_TREE_WAVES 5               /* waves per SIMD the tree kernel is compiled for (0: compiler's choice); its LDS
                                        * (stacks + leaf-pass slots, 30 KB per workgroup for a 26-level tree) allows 5 */
 #endif
+#ifndef RT_TREE_SPECULATE
+#define RT_TREE_SPECULATE 0           /* 1: request both children's records while the visited node's boxes are tested */
+#endif
 #ifndef RT_TREE_LEAF_MIN
 #define RT_TREE_LEAF_MIN 16           /* rays waiting at a leaf that make a leaf pass worth running beside node steps */
 #endif
-#define RT_TREE_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * 256u * 4u)   /* bytes per workgroup for the leaf passes */
-#define RT_LEAF_WORDS_PER_WAVE 256u   /* LDS words per wave for the leaf passes: 64 keys (2 words) + 64 x (beta, gamma) */
+#ifndef RT_TREE_TOP
+#define RT_TREE_TOP 0                 /* node records of the tree tops kept in LDS per workgroup (shared by up to two meshes); 0: none */
+#endif
+#ifndef RT_LEAF_MARKS
+#define RT_LEAF_MARKS 1               /* leaf passes find the owner of a pair from a byte table of first pairs (0: binary search by lane exchange) */
+#endif
+#ifndef RT_LEAF_REDO
+#define RT_LEAF_REDO 0                /* the ray that accepted a triangle computes its barycentrics again (0: the pair that won leaves them in LDS) */
+#endif
+#define RT_LEAF_WORDS_PER_WAVE (128u + (RT_LEAF_REDO ? 0u : 128u) + (RT_LEAF_MARKS ? 32u : 0u))   /* LDS words per wave for the leaf passes: 64 keys (2 words), 1024 mark bits, 64 x (beta, gamma) */
+#define RT_TREE_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * RT_LEAF_WORDS_PER_WAVE * 4u + (size_t)RT_TREE_TOP * 64u)   /* bytes per workgroup for the leaf passes and the tree tops */
 #if RT_TREE_WAVES
 #define RT_TREE_ATTR __attribute__((amdgpu_waves_per_eu(RT_TREE_WAVES, RT_TREE_WAVES)))
 #else
@@ -515,8 +527,25 @@ rt_tree_kernel(const TreeParams P)
     /* after the stacks: per wave 64 keys (8 bytes) and 64 barycentric pairs for the leaf passes */
     uint32_t *leaf_area = lds + (size_t)RT_BLOCK * P.S.stack_cap + (threadIdx.x >> 6) * RT_LEAF_WORDS_PER_WAVE;
     unsigned long long *leaf_best = reinterpret_cast<unsigned long long *>(leaf_area);
-    float *leaf_bary = reinterpret_cast<float *>(leaf_area + 128);
+    uint32_t *leaf_marks = leaf_area + 128;              /* 32 words (if RT_LEAF_MARKS) */
+    float *leaf_bary = reinterpret_cast<float *>(leaf_area + 128 + (RT_LEAF_MARKS ? 32 : 0));   /* 128 words (unless RT_LEAF_REDO) */
+    (void)leaf_bary; (void)leaf_marks;
 
+#if RT_TREE_TOP
+    /* The first records of a mesh's node range are the top levels of its tree (breadth-first order): every walk
+     * passes through them.  Each workgroup keeps a copy in LDS, so those visits cost an LDS read instead of a
+     * 64-byte line through the vector memory pipeline. */
+    uint32_t *tops = lds + (size_t)RT_BLOCK * P.S.stack_cap + (RT_BLOCK / 64) * RT_LEAF_WORDS_PER_WAVE;
+    const uint32_t top_meshes = P.S.mesh_count < 2 ? (uint32_t)P.S.mesh_count : 2u;
+    const uint32_t top_each = top_meshes ? RT_TREE_TOP / top_meshes : 0u;
+    for (uint32_t m = 0; m < top_meshes; m++) {
+        const uint32_t n = P.S.meshes[m].node_count < top_each ? P.S.meshes[m].node_count : top_each;
+        const rt::u32x4 *src = reinterpret_cast<const rt::u32x4 *>(P.S.nodes + P.S.meshes[m].node_base);
+        rt::u32x4 *dst = reinterpret_cast<rt::u32x4 *>(tops + (size_t)m * top_each * 16u);
+        for (uint32_t i = threadIdx.x; i < n * 4u; i += RT_BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+#endif
     bool busy = false, any_hit = false;
     uint32_t slot = 0;
     rt::f3 o = rt::mk(0, 0, 0), d = rt::mk(0, 0, 0);
@@ -528,6 +557,12 @@ rt_tree_kernel(const TreeParams P)
     uint32_t cur = RT_ENTRY_NONE;                        /* entry the lane visits next; its record is in ra..rd */
     rt::u32x4 ra = 0, rb = 0, rc = 0, rd = 0;
     bool stepped = false;                                /* the lane needs its next record */
+#if RT_TREE_SPECULATE
+    /* the records of the visited node's interior children, requested before its boxes are tested: whichever
+     * child the walk turns to next, its record has had the whole box test to arrive */
+    uint32_t spec0 = RT_ENTRY_NONE, spec1 = RT_ENTRY_NONE;
+    rt::u32x4 s0a = 0, s0b = 0, s0c = 0, s0d = 0, s1a = 0, s1b = 0, s1c = 0, s1d = 0;
+#endif
 
     auto finish = [&]() {                                /* answer the query: write the hit back */
         uint4 *q = reinterpret_cast<uint4 *>(P.list + (size_t)slot * RT_RECORD_WORDS);
@@ -596,11 +631,20 @@ rt_tree_kernel(const TreeParams P)
             }
             const uint32_t first = incl - count;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            /* owners packed to the low lanes (a permutation of the wave), for the search below */
+            /* owners packed to the low lanes in lane order (= order of their first pairs): packed owner i is
+             * the i-th ray with pairs */
             const uint32_t dest = want_tri ? (uint32_t)__popcll(tri_mask & lanes_below)
                                            : (uint32_t)n_tri + (uint32_t)__popcll(~tri_mask & lanes_below);
-            const uint32_t packed_first = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest * 4u), want_tri ? (int)first : -1);
             const uint32_t packed_lane = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest * 4u), (int)lane);
+#if RT_LEAF_MARKS
+            /* which ray owns pair k: the rays mark their first pairs in a bit table (at most 64 x 16 pairs); the 64 bits
+             * of a step's pairs number the owners: no search */
+            if (lane < 32u) leaf_marks[lane] = 0u;
+            if (want_tri) __hip_atomic_fetch_or(leaf_marks + (first >> 5), 1u << (first & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t owners_before = 0;
+#else
+            const uint32_t packed_first = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest * 4u), want_tri ? (int)first : -1);
+#endif
             unsigned long long *best = leaf_best + lane;     /* this lane's slot as an owner */
             /* closest-hit rays: key = bits of t << 32 | (0xFFFFFFFE - place): smallest t, ties to the later triangle.
              * any-hit rays stop at the first accepted triangle: key = place << 32 | bits of t.  0 = walk one by one. */
@@ -609,12 +653,19 @@ rt_tree_kernel(const TreeParams P)
             const uint32_t tri_first = (tv.tri_base + tv.tri_cur) | (any_hit ? 0x80000000u : 0u);
             for (uint32_t base = 0; base < total; base += 64u) {
                 const uint32_t k = base + lane;
+#if RT_LEAF_MARKS
+                const uint32_t starts_lo = leaf_marks[base >> 5], starts_hi = leaf_marks[(base >> 5) + 1u];   /* the same words for every lane */
+                const unsigned long long upto = lanes_below | (1ull << lane);
+                const uint32_t pos = owners_before + (uint32_t)__popc(starts_lo & (uint32_t)upto) + (uint32_t)__popc(starts_hi & (uint32_t)(upto >> 32)) - 1u;
+                owners_before += (uint32_t)__popc(starts_lo) + (uint32_t)__popc(starts_hi);
+#else
                 uint32_t pos = 0;                            /* last packed owner whose first pair is <= k */
                 for (uint32_t step = 32u; step; step >>= 1) {
                     const uint32_t probe = pos + step;
                     const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(probe * 4u), (int)packed_first);
                     if (v <= k) pos = probe;
                 }
+#endif
                 const uint32_t owner = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos * 4u), (int)packed_lane);
                 const int from = (int)(owner * 4u);
                 const uint32_t own_first = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)first);
@@ -642,18 +693,23 @@ rt_tree_kernel(const TreeParams P)
                         const unsigned long long key = verdict == rt::PAIR_UNORDERED ? 0ull
                             : own_any ? (((unsigned long long)place << 32) | (unsigned long long)__float_as_uint(t))
                                       : (((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(0xFFFFFFFEu - place));
+#if RT_LEAF_REDO
+                        __hip_atomic_fetch_min(slot_best, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   /* result unused: no wait */
+#else
                         atomicMin(slot_best, key);
                         /* a minimum with all-ones changes nothing and returns the slot as an LDS operation, in order behind
                          * the wave's updates above */
                         if (key && atomicMin(slot_best, ~0ull) == key) {                 /* best so far: leave the barycentrics */
                             leaf_bary[2 * owner] = beta; leaf_bary[2 * owner + 1] = gamma;
                         }
+#endif
                     }
                 }
             }
             if (want_tri) {
                 const unsigned long long key = atomicMin(best, ~0ull);
                 bool accepted = false;
+                uint32_t place = 0;
                 if (key == 0ull) {                           /* unordered distance somewhere: the host's one-by-one walk */
                     while (tv.tri_cur < tv.tri_end) {
                         const int r = rt::query_tri_step<STATS>(P.S, any_hit, h, tv, cn);
@@ -663,19 +719,30 @@ rt_tree_kernel(const TreeParams P)
                 } else if (any_hit) {
                     const uint32_t count_here = tv.tri_end - tv.tri_cur;
                     if (key != ~0ull) {
-                        const uint32_t place = (uint32_t)(key >> 32);
+                        place = (uint32_t)(key >> 32);
                         h.type = rt::HIT_TRIANGLE; h.t = __uint_as_float((uint32_t)key);
                         h.id = tv.tri_cur + place; h.inst = (uint32_t)tv.inst;
-                        h.beta = leaf_bary[2 * lane]; h.gamma = leaf_bary[2 * lane + 1]; h.material = tv.material;
+                        h.material = tv.material;
                         accepted = true;
                         if (STATS) cn.tri_tests += place + 1u;   /* the host stops at this triangle */
                     } else if (STATS) cn.tri_tests += count_here;
                 } else if ((uint32_t)key != 0xFFFFFFFFu) {
-                    const uint32_t place = 0xFFFFFFFEu - (uint32_t)key;
+                    place = 0xFFFFFFFEu - (uint32_t)key;
                     h.type = rt::HIT_TRIANGLE; h.t = __uint_as_float((uint32_t)(key >> 32));
                     h.id = tv.tri_cur + place; h.inst = (uint32_t)tv.inst;
-                    h.beta = leaf_bary[2 * lane]; h.gamma = leaf_bary[2 * lane + 1]; h.material = tv.material;
+                    h.material = tv.material;
                     accepted = true;
+                }
+                if (accepted && key != 0ull) {
+#if RT_LEAF_REDO
+                    /* the winner's barycentrics: the same operations on the same operands again give the same bits
+                     * (cheaper than a second pass of LDS traffic for every pair, since few leaf visits end in a hit) */
+                    const rt::u32x4 *q = reinterpret_cast<const rt::u32x4 *>(P.S.tris + tv.tri_base + tv.tri_cur + place);
+                    float t2;
+                    (void)rt::leaf_pair(q[0], q[1], q[2], tv.mo, tv.mu, 3.402823466e+38f, t2, h.beta, h.gamma);
+#else
+                    h.beta = leaf_bary[2 * lane]; h.gamma = leaf_bary[2 * lane + 1];
+#endif
                 }
                 tv.tri_cur = tv.tri_end;
                 stepped = true;
@@ -684,15 +751,48 @@ rt_tree_kernel(const TreeParams P)
         }
         if (run_node) {
             if (STATS) { if (lane == 0) cn.pop_steps++; if (want_node) cn.pop_lanes++; }
-            if (want_node) { rt::walk_node<STATS>(ra, rb, rc, rd, h, tv, stk, cur, cn); stepped = true; }
+            if (want_node) {
+#if RT_TREE_SPECULATE
+                spec0 = (rd.x & RT_ENTRY_LEAF) ? RT_ENTRY_NONE : rd.x;
+                spec1 = (rd.y & RT_ENTRY_LEAF) ? RT_ENTRY_NONE : rd.y;
+                if (spec0 != RT_ENTRY_NONE) {
+                    const rt::u32x4 *q = reinterpret_cast<const rt::u32x4 *>(P.S.nodes + tv.node_base + spec0);
+                    s0a = q[0]; s0b = q[1]; s0c = q[2]; s0d = q[3];
+                }
+                if (spec1 != RT_ENTRY_NONE) {
+                    const rt::u32x4 *q = reinterpret_cast<const rt::u32x4 *>(P.S.nodes + tv.node_base + spec1);
+                    s1a = q[0]; s1b = q[1]; s1c = q[2]; s1d = q[3];
+                }
+#endif
+                rt::walk_node<STATS>(ra, rb, rc, rd, h, tv, stk, cur, cn); stepped = true;
+            }
         }
         /* ---- the one place records are requested: every lane that took a step (or a new ray) ---- */
         if (stepped) {
             stepped = false;
             const rt::u32x4 *q = nullptr;
+#if RT_TREE_SPECULATE
+            const uint32_t child = cur;                  /* the child the node step turned to (none: the stack or the next instance decide) */
+#endif
             const int next = rt::walk_advance<STATS>(P.S, o, d, h, tv, stk, cur, q, cn);
-            if (next == rt::NEXT_NODE) { ra = q[0]; rb = q[1]; rc = q[2]; rd = q[3]; }
+            if (next == rt::NEXT_NODE) {
+#if RT_TREE_SPECULATE
+                if (child != RT_ENTRY_NONE && child == spec0) { ra = s0a; rb = s0b; rc = s0c; rd = s0d; }
+                else if (child != RT_ENTRY_NONE && child == spec1) { ra = s1a; rb = s1b; rc = s1c; rd = s1d; }
+                else
+#endif
+#if RT_TREE_TOP
+                if (tv.mesh < top_meshes && cur < top_each) {
+                    const rt::u32x4 *t = reinterpret_cast<const rt::u32x4 *>(tops + ((size_t)tv.mesh * top_each + cur) * 16u);
+                    ra = t[0]; rb = t[1]; rc = t[2]; rd = t[3];
+                } else
+#endif
+                { ra = q[0]; rb = q[1]; rc = q[2]; rd = q[3]; }
+            }
             else if (next == rt::NEXT_DONE) finish();
+#if RT_TREE_SPECULATE
+            spec0 = spec1 = RT_ENTRY_NONE;
+#endif
         }
     }
     flush_counters<STATS>(cn, P.stats);
@@ -1169,6 +1269,9 @@ int rt_gpu_device_count(void)
 
 const char *rt_gpu_last_error(void) { return g_error.c_str(); }
 
+/* for the library's other translation units (not part of the public header) */
+int rt_gpu_set_error(int code, const char *what) { return fail(code, what ? what : ""); }
+
 static void free_lane(BatchLane &L)
 {
     if (L.d_samples) (void)hipFree(L.d_samples);
@@ -1230,6 +1333,10 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
     rt_flat_scene flat;
     if (rt_flatten_scene(scene, flat) != 0) return fail(RT_GPU_ERR_SCENE, "scene rejected: " + flat.error);
 
+    /* a parked path record keeps the instance to walk and the light being sampled in 16 bits each */
+    if (flat.instances.size() > 0xFFFEu) return fail(RT_GPU_ERR_SCENE, "scene rejected: more than 65534 mesh instances");
+    if (flat.lights.size() > 0xFFFFu) return fail(RT_GPU_ERR_SCENE, "scene rejected: more than 65535 lights");
+
     rt_gpu_scene *s = new rt_gpu_scene();
     int rc = 0;
     do {
@@ -1258,6 +1365,7 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
             s->specular = any;
         }
         s->dev.texture_count = (int32_t)flat.textures.size();
+        s->dev.mesh_count = (int32_t)flat.meshes.size();
         s->dev.stack_cap = flat.stack_cap;
         if ((rc = upload(s, flat.lights, &s->dev.lights))) break;
         if ((rc = upload(s, flat.spheres, &s->dev.spheres))) break;
@@ -1572,7 +1680,8 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     RT_HIP(hipEventRecord(s->ev_start, caller));
     hipEvent_t previous_sum = nullptr;                   /* per-pixel sums run in batch order: a pixel's samples are added in sample order */
     for (uint64_t batch = 0, first64 = 0; first64 < total_spp; batch++, first64 += batch_spp) {
-        BatchLane &L = s->lanes[(first_lane + batch) % K.lanes];
+        BatchLane &L = s->lanes[(first_lane + batch % lanes_used) % K.lanes];     /* only the lanes whose work memory was made ready above */
+        if (!L.d_samples || !L.d_parked[0] || !L.d_parked[1] || !L.d_rounds) return fail(RT_GPU_ERR_DEVICE, "internal: batch lane without work memory");
         hipStream_t stream = L.stream;
         if (batch < lanes_used) RT_HIP(hipStreamWaitEvent(stream, s->ev_start, 0));
         const uint32_t first = (uint32_t)first64;
@@ -1671,6 +1780,7 @@ int rt_gpu_render_region_static(rt_gpu_scene *s, float *device_pixels, uint32_t 
     if (width > 0xFFFFu || height > 0xFFFFu) return fail(RT_GPU_ERR_ARGUMENT, "image sides above 65535 are not supported");
     if (o && o->frames > 1) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_render_region_static renders one frame per call");
     if ((uint64_t)spp + (o ? o->sample_offset : 0) > 0xFFFFFFFFull) return fail(RT_GPU_ERR_ARGUMENT, "sample indices exceed 32 bits");
+    if (o && o->max_segments >= (1u << 24)) return fail(RT_GPU_ERR_ARGUMENT, "max_segments must be below 2^24");
     RenderParams G;
     memset(&G, 0, sizeof(G));
     uint32_t own_rows = 0;

@@ -19,6 +19,7 @@
 
 #define LEAF_MAX_TRIANGLES 16u      /* src/main.c:120 */
 #define SPLIT_RETRY_LIMIT 200       /* the reference retries forever on coincident centroids */
+#define TREE_DEPTH_LIMIT 4096u      /* the reference recurses without bound; no real model comes near (the dog: 24 levels) */
 
 typedef struct node_pool { rt_mesh_node *nodes; size_t used, cap; } node_pool;
 
@@ -46,6 +47,7 @@ static void build_node(rt_mesh_node *node, rt_mesh *mesh, uint32_t depth, node_p
 
     uint32_t first = node->first_triangle_id, last = node->last_triangle_id;
     if (last - first + 1 <= LEAF_MAX_TRIANGLES) return;
+    if (depth >= TREE_DEPTH_LIMIT) return;          /* degenerate geometry (one triangle split off per level): a large leaf ends the recursion */
 
     int axis = 0;
     if (axis_of(&box.max, 1) - axis_of(&box.min, 1) > axis_of(&box.max, axis) - axis_of(&box.min, axis)) axis = 1;
@@ -110,18 +112,20 @@ int rt_host_mesh_build_tree(rt_mesh *mesh)
 int rt_host_mesh_from_obj_arrays(const float *positions, uint32_t position_count,
                                  const float *texcoords, uint32_t texcoord_count,
                                  const float *normals, uint32_t normal_count,
-                                 const uint32_t *indices_ptn, const uint32_t *face_vertices,
-                                 uint32_t face_count, rt_mesh *out)
+                                 const uint32_t *indices_ptn, uint64_t index_count,
+                                 const uint32_t *face_vertices, uint32_t face_count, rt_mesh *out)
 {
     if (!positions || !indices_ptn || !face_vertices || !out) return -1;
     memset(out, 0, sizeof(*out));
 
-    uint64_t tri_total = 0;
+    uint64_t tri_total = 0, corners = 0;
     for (uint32_t i = 0; i < face_count; i++) {
         if (face_vertices[i] < 3) return -3;
         tri_total += face_vertices[i] - 2;
+        corners += face_vertices[i];
     }
     if (tri_total == 0 || tri_total > 0x07FFFFFFu) return -4;
+    if (corners > index_count) return -6;          /* the faces name more corners than the index table holds */
 
     out->point_count = position_count;
     out->texcoord_count = texcoord_count;

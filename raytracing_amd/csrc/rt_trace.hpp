@@ -283,6 +283,7 @@ struct Trav {
     int top;                     /* stack pointer, -1 = empty */
     int inst;                    /* instance being walked / next to scan */
     int material;
+    uint32_t mesh;               /* index of the instance's mesh (tree kernel: which staged tree top is its own) */
     f3 inv;                      /* refined reciprocals of mu (only if cached) */
     bool cached;                 /* the shared-reciprocal slab test is exact for this ray and mesh */
 };
@@ -373,6 +374,7 @@ __device__ __forceinline__ bool query_scan(const rt_dev_scene &S, f3 o, f3 d, co
         if (enter > h.t) continue;
         tv.node_base = m.node_base; tv.tri_base = m.tri_base; tv.material = in.material;
         tv.top = 0; tv.tri_cur = 0; tv.tri_end = 0;
+        tv.mesh = in.mesh;
         tv.cached = false;
         if (CACHE) {
             tv.cached = m.tame_boxes != 0u && tame(tv.mu.x) && tame(tv.mu.y) && tame(tv.mu.z) &&

@@ -24,6 +24,8 @@ EXPORTS = [
     "rt_gpu_device_count", "rt_gpu_last_error", "rt_gpu_scene_create", "rt_gpu_scene_destroy",
     "rt_gpu_scene_set_camera", "rt_gpu_render_region", "rt_gpu_render_region_device", "rt_gpu_render_region_static",
     "rt_gpu_normalize_device", "rt_gpu_render_jobs", "rt_gpu_find_ray_hit", "rt_gpu_find_ray_hit_serial", "rt_gpu_quantize", "rt_gpu_quantize_device",
+    "rt_gpu_multi_create", "rt_gpu_multi_destroy", "rt_gpu_multi_device_count", "rt_gpu_multi_render_frame",
+    "rt_gpu_multi_rows_per_rank", "rt_gpu_assemble_bands_device",
     "rt_gpu_get_stats", "rt_gpu_get_stats_by_kernel", "rt_gpu_reset_stats", "rt_gpu_eval_math",
 ]
 
@@ -92,6 +94,14 @@ def lib():
         L.rt_gpu_quantize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.rt_gpu_quantize_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rt_gpu_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.rt_gpu_multi_create.argtypes = [C.POINTER(T.Scene), C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_gpu_multi_destroy.argtypes = [C.c_void_p]
+        L.rt_gpu_multi_destroy.restype = None
+        L.rt_gpu_multi_device_count.argtypes = [C.c_void_p]
+        L.rt_gpu_multi_render_frame.argtypes = [C.c_void_p, C.POINTER(T.Image3f), C.c_uint32, C.c_uint64, C.POINTER(Options)]
+        L.rt_gpu_multi_rows_per_rank.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.rt_gpu_multi_rows_per_rank.restype = C.c_uint32
+        L.rt_gpu_assemble_bands_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.rt_gpu_get_stats_by_kernel.argtypes = [C.c_void_p, C.POINTER(Stats * 4)]
         L.rt_gpu_reset_stats.argtypes = [C.c_void_p]
         L.rt_gpu_eval_math.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
@@ -174,6 +184,38 @@ class GpuScene:
 
     def reset_stats(self):
         _check(lib().rt_gpu_reset_stats(self._h))
+
+
+class MultiGpuFrame:
+    """rt_gpu_multi_*: one frame over `device_count` GPUs of the node from this process (0 = all visible)."""
+
+    def __init__(self, scene_handle, device_count=0):
+        self._keep = scene_handle
+        self._h = C.c_void_p()
+        _check(lib().rt_gpu_multi_create(scene_handle.ptr, device_count, C.byref(self._h)))
+
+    @property
+    def device_count(self):
+        return lib().rt_gpu_multi_device_count(self._h)
+
+    def render_frame(self, image, spp, seed, options=None):
+        _check(lib().rt_gpu_multi_render_frame(self._h, C.byref(image), spp, seed,
+                                               C.byref(options) if options is not None else None))
+
+    def close(self):
+        if self._h:
+            lib().rt_gpu_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def assemble_bands_device(all_ptr, frame_ptr, width, height, band_rows, world, stream=0):
+    _check(lib().rt_gpu_assemble_bands_device(all_ptr, frame_ptr, width, height, band_rows, world, C.c_void_p(stream)))
 
 
 def normalize_device(device_ptr, pixel_count, spp_total, stream=0):

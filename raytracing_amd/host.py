@@ -25,7 +25,7 @@ def lib():
         L.rt_host_mesh_build_tree.restype = C.c_int
         L.rt_host_mesh_from_obj_arrays.argtypes = [
             C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
-            C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(T.Mesh)]
+            C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(T.Mesh)]
         L.rt_host_mesh_from_obj_arrays.restype = C.c_int
         L.rt_host_mesh_free.argtypes = [C.POINTER(T.Mesh)]
         L.rt_host_mesh_free.restype = None
@@ -50,10 +50,12 @@ def mesh_from_obj_arrays(positions, texcoords, normals, indices_ptn, face_vertic
     normals = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
     indices_ptn = np.ascontiguousarray(indices_ptn, dtype=np.uint32).reshape(-1, 3)
     face_vertices = np.ascontiguousarray(face_vertices, dtype=np.uint32)
+    if int(face_vertices.sum(dtype=np.uint64)) > len(indices_ptn):
+        raise ValueError(f"the faces name {int(face_vertices.sum(dtype=np.uint64))} corners, the index table holds {len(indices_ptn)}")
     mesh = T.Mesh()
     rc = lib().rt_host_mesh_from_obj_arrays(
         positions.ctypes.data, len(positions), texcoords.ctypes.data, len(texcoords),
-        normals.ctypes.data, len(normals), indices_ptn.ctypes.data, face_vertices.ctypes.data,
+        normals.ctypes.data, len(normals), indices_ptn.ctypes.data, len(indices_ptn), face_vertices.ctypes.data,
         len(face_vertices), C.byref(mesh))
     if rc != 0:
         raise RuntimeError(f"rt_host_mesh_from_obj_arrays failed: {rc}")

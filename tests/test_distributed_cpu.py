@@ -114,3 +114,17 @@ def test_sample_split_partial_sums_three_ranks():
     assert [multi_gpu.sample_range(r, 3, 64) for r in range(3)] == [(0, 22), (22, 21), (43, 21)]
     assert sum(multi_gpu.sample_range(r, 8, 64)[1] for r in range(8)) == 64
     assert multi_gpu.pixel_norm(64) == np.float32(1.0 / (0.5 * np.pi * 64))
+
+
+def test_c_side_band_layout_matches_the_python_split():
+    """rt_gpu_multi_rows_per_rank (the packed buffer height the C multi-GPU entry gathers) against
+    rows_of_rank for even and ragged heights; needs no GPU (pure arithmetic in the library)."""
+    from raytracing_amd import gpu, multi_gpu
+    lib = gpu.lib()
+    for height in (8, 61, 64, 128, 1000, 1024, 4096):
+        for world in (1, 2, 3, 4, 8):
+            rows = lib.rt_gpu_multi_rows_per_rank(height, 8, world)
+            owned = [len(multi_gpu.rows_of_rank(r, world, height)) for r in range(world)]
+            assert rows >= max(owned) and rows % 8 == 0 and rows - max(owned) < 8 + 8 * (max(owned) % 8 != 0), (height, world, rows, owned)
+            if height % (8 * world) == 0:
+                assert rows == multi_gpu.packed_rows(world, height)

@@ -445,6 +445,44 @@ def test_band_split_is_invisible(gpu_scenes, world):
     assert L.same_bits(multi_gpu.assemble(gathered, world, H, W).cpu().numpy(), whole).all()
 
 
+def test_c_side_multi_gpu_frame(gpu_scenes):
+    """rt_gpu_multi_* (the single-process C entry for a node's GPUs).  This box has one GPU, so: the whole
+    entry with one device (scene per device, band render, gather step, assembly, copy to the host image)
+    gives rt_gpu_render_region's frame bit for bit on a height that is no multiple of the band; the
+    assembly kernel alone, fed the packed band buffers of 3 and 4 ranks rendered one after the other on
+    this GPU (ragged last band, padding rows), gives the same frame; asking for more devices than are
+    visible is an error."""
+    import torch
+    sh, gs = gpu_scenes("three_dogs")
+    W, H, spp, seed = 72, 61, 3, 8
+    whole_img, whole = host.new_image(W, H)
+    gs.render_region(whole_img, (0, 0, W, H), spp, seed)
+    m = gpu.MultiGpuFrame(sh, 1)
+    assert m.device_count == 1
+    img, got = host.new_image(W, H)
+    m.render_frame(img, spp, seed)
+    assert L.same_bits(got, whole).all()
+    m.render_frame(img, spp, seed, gpu.Options(sample_offset=4))          # a second frame on the same object, other samples
+    img2, want2 = host.new_image(W, H)
+    gs.render_region(img2, (0, 0, W, H), spp, seed, gpu.Options(sample_offset=4))
+    assert L.same_bits(got, want2).all()
+    with pytest.raises(gpu.GpuError, match="no bands"):
+        m.render_frame(img, spp, seed, gpu.Options(band_rows=8, band_count=2))
+    m.close()
+    for world in (3, 4):
+        rows = gpu.lib().rt_gpu_multi_rows_per_rank(H, 8, world)
+        everything = torch.zeros((world, rows, W, 3), dtype=torch.float32, device="cuda")
+        for r in range(world):
+            o = gpu.Options(band_rows=8, band_rank=r, band_count=world, flags=gpu.FLAG_COMPACT_BANDS)
+            gs.render_region_device(everything[r].data_ptr(), W, H, (0, 0, W, H), spp, seed, o)
+        frame = torch.full((H, W, 3), -1.0, dtype=torch.float32, device="cuda")
+        gpu.assemble_bands_device(everything.data_ptr(), frame.data_ptr(), W, H, 8, world)
+        torch.cuda.synchronize()
+        assert L.same_bits(frame.cpu().numpy(), whole).all(), world
+    with pytest.raises(gpu.GpuError, match="visible"):
+        gpu.MultiGpuFrame(sh, gpu.lib().rt_gpu_device_count() + 1)
+
+
 def test_sample_split_equals_the_frame_up_to_summation_order(gpu_scenes):
     """The other split over devices: rank r adds samples [first, first + count) of every pixel to zeros,
     the partial sums are added in rank order and scaled once.  Each partial sum is the oracle's own
@@ -555,6 +593,16 @@ def test_errors_are_reported_not_crashed(gpu_scenes):
     o.struct_size = 3
     with pytest.raises(gpu.GpuError, match="struct_size"):
         gs.render_region(img, (0, 0, 16, 16), 1, 0, o)
+    with pytest.raises(gpu.GpuError, match="max_segments"):
+        gs.render_region(img, (0, 0, 16, 16), 1, 0, gpu.Options(max_segments=1 << 24))
+    with pytest.raises(gpu.GpuError, match="options.lane"):
+        gs.render_region(img, (0, 0, 16, 16), 1, 0, gpu.Options(lane=8))
+    # a parked record holds the light index in 16 bits: more lights than that are refused, not mis-rendered
+    many = scenes.sphere_room()
+    lights = (T.Light * 65536)(*([scenes.room_lights()[0]] * 65536))
+    many.scene.light_count, many.scene.lights = 65536, lights
+    with pytest.raises(gpu.GpuError, match="65535 lights"):
+        gpu.GpuScene(many)
 
 
 # ---------------------------------------------------------------- Monte Carlo agreement at equal sample count

@@ -65,6 +65,14 @@ def test_small_meshes_and_polygons():
         ids = np.array([[[i + 1, 0, 0], [i + 2, 0, 0], [i + 3, 0, 0]] for i in range(n)], np.uint32).reshape(-1, 3)
         return host.mesh_from_obj_arrays(p, np.zeros((1, 2), np.float32), np.zeros((1, 3), np.float32), ids,
                                          np.full(n, 3, np.uint32))
+    # an index table shorter than the faces claim is refused, by the binding and by the C function itself
+    with pytest.raises(ValueError, match="corners"):
+        host.mesh_from_obj_arrays(pos, tc, nr, idx[:8], np.array([4, 5], np.uint32))
+    bad = T.Mesh()
+    fv = np.array([4, 5], np.uint32)
+    assert host.lib().rt_host_mesh_from_obj_arrays(pos.ctypes.data, len(pos), tc.ctypes.data, len(tc), nr.ctypes.data, len(nr),
+                                                   idx.ctypes.data, 8, fv.ctypes.data, 2, C.byref(bad)) == -6
+
     m16, m17 = strip(16), strip(17)
     assert host.mesh_census(m16) == dict(nodes=1, leaves=1, depth=1, max_leaf=16)
     c17 = host.mesh_census(m17)

@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
-"""One benchmark frame with the detailed counters: rounds, kernel shares, tree step occupancy."""
+"""Benchmark frames one at a time with every launch timed: device time per kind of launch, rounds;
+then one frame with the detailed counters: work counts and scheduler step occupancy.
+environment: SCENE, SIZE, SPP, FRAMES; RT_GPU_LIB selects a library variant."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raytracing_amd import gpu, scenes
-W = H = int(os.environ.get("SIZE", "1024")); spp = int(os.environ.get("SPP", "64"))
+W = H = int(os.environ.get("SIZE", "1024")); spp = int(os.environ.get("SPP", "64")); n = int(os.environ.get("FRAMES", "4"))
 sh = scenes.CONFIGS[os.environ.get("SCENE", "dog_room")]()
 g = gpu.GpuScene(sh)
 buf = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
-for detailed in (False, True):
-    g.reset_stats()
+g.render_region_device(buf.data_ptr(), W, H, (0, 0, W, H), spp, 0, gpu.Options(sample_offset=999 * spp))
+torch.cuda.synchronize()
+g.reset_stats()
+wall = []
+for k in range(n):
     torch.cuda.synchronize(); t = time.perf_counter()
-    g.render_region_device(buf.data_ptr(), W, H, (0, 0, W, H), spp, 0,
-                           gpu.Options(flags=gpu.FLAG_DETAILED_STATS if detailed else 0))
-    torch.cuda.synchronize(); dt = time.perf_counter() - t
+    g.render_region_device(buf.data_ptr(), W, H, (0, 0, W, H), spp, 0, gpu.Options(flags=gpu.FLAG_KERNEL_TIMES, sample_offset=k * spp))
+    torch.cuda.synchronize(); wall.append(1e3 * (time.perf_counter() - t))
+st, by = g.stats(), g.stats_by_kernel()
+print(f"plain: wall {sorted(wall)[len(wall) // 2]:.2f} ms median; " + ", ".join(f"{k} {by[k]['kernel_ms'] / n:.2f}" for k in gpu.KERNEL_KINDS) +
+      f" ms; sum {st['kernel_ms'] / n:.2f} ms; rounds {st['rounds'] / n:.1f}, batches {st['launches'] / n:.1f}, rays {st['rays'] / n / 1e6:.1f} M, checksum {float(buf.double().sum()):.6f}")
+if not os.environ.get("PLAIN_ONLY"):
+    g.reset_stats()
+    g.render_region_device(buf.data_ptr(), W, H, (0, 0, W, H), spp, 0, gpu.Options(flags=gpu.FLAG_DETAILED_STATS))
+    torch.cuda.synchronize()
     st = g.stats()
-    print(f"detailed={detailed}: wall {1e3*dt:.1f} ms, shade {st['shade_ms']:.1f} ms, tree {st['tree_ms']:.1f} ms, "
-          f"rounds {st['rounds']}, overflowed {st['overflowed']}, rays {st['rays']/1e6:.1f} M")
-    if detailed:
-        print({k: st[k] for k in ("tree_entries", "interior_pops", "leaf_pops", "tri_tests", "root_tests")})
-        print({k: st[k] for k in ("samples", "rays", "shadow_rays", "rng_draws", "light_tests", "plane_tests", "tri_hits")})
-        for kind in ("shade", "pop", "tri"):
-            steps, lanes = st[kind + "_steps"], st[kind + "_lanes"]
-            print(f"  {kind}: {steps} wave steps, {lanes / max(1, steps):.1f} lanes per step")
+    print({k: st[k] for k in ("tree_entries", "interior_pops", "leaf_pops", "tri_tests", "root_tests")})
+    print({k: st[k] for k in ("samples", "rays", "shadow_rays", "rng_draws", "light_tests", "plane_tests", "tri_hits")})
+    for kind in ("shade", "pop", "tri"):
+        steps, lanes = st[kind + "_steps"], st[kind + "_lanes"]
+        print(f"  {kind}: {steps} wave steps, {lanes / max(1, steps):.1f} lanes per step")
+g.close()
