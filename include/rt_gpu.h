@@ -120,6 +120,17 @@ const char *rt_gpu_last_error(void);
 int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out);
 void rt_gpu_scene_destroy(rt_gpu_scene *scene);
 
+/* What making the scene resident cost and what it holds. */
+typedef struct rt_gpu_scene_info_t {
+    double   flatten_ms;       /* host: walking the scene graph into flat arrays */
+    double   upload_ms;        /* device allocations, copies, streams and events */
+    uint64_t resident_bytes;   /* tree nodes, triangles, attributes and texels in HBM */
+    uint64_t work_bytes;       /* work memory the render calls so far have made the handle allocate (all lanes) */
+    uint32_t mesh_count, instance_count, texture_count;   /* distinct meshes and textures after de-duplication */
+    uint32_t stack_levels;     /* traversal stack entries per ray */
+} rt_gpu_scene_info_t;
+int rt_gpu_scene_info(const rt_gpu_scene *scene, rt_gpu_scene_info_t *out);
+
 /* Replace the camera of a resident scene (Scene.camera, src/main.h:9). */
 int rt_gpu_scene_set_camera(rt_gpu_scene *scene, const void *camera /* Camera, 40 bytes */);
 

@@ -16,7 +16,10 @@
 
 #include <cmath>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
 #include <map>
+#include <thread>
 #include <queue>
 
 namespace {
@@ -219,38 +222,56 @@ int rt_flatten_scene(const rt_scene *scene, rt_flat_scene &out)
             dm.node_base = (uint32_t)out.nodes.size();
             st(dm.root_lo, ld(mesh->root.bbox.min)); st(dm.root_hi, ld(mesh->root.bbox.max));
 
-            for (uint32_t f = 0; f < mesh->face_count; f++) {
-                const rt_triangle &tri = mesh->faces[f];
-                for (int k = 0; k < 3; k++) {
-                    if (tri.ids[k].vertexId >= mesh->point_count ||
-                        (mesh->normals && tri.ids[k].normalId >= mesh->normal_count) ||
-                        (mesh->texcoords && tri.ids[k].texcoordId >= mesh->texcoord_count)) {
-                        out.error = "triangle with an index outside its attribute table"; return -2;
+            /* one record pair per triangle, gathered through the face's indices; the faces are independent, so
+             * large meshes are cut into ranges that a few threads fill side by side */
+            const size_t tri0 = out.tris.size();
+            out.tris.resize(tri0 + mesh->face_count);
+            out.attrs.resize(tri0 + mesh->face_count);
+            std::atomic<bool> bad_index(false);
+            auto gather = [&](uint32_t from, uint32_t to) {
+                for (uint32_t f = from; f < to; f++) {
+                    const rt_triangle &tri = mesh->faces[f];
+                    for (int k = 0; k < 3; k++) {
+                        if (tri.ids[k].vertexId >= mesh->point_count ||
+                            (mesh->normals && tri.ids[k].normalId >= mesh->normal_count) ||
+                            (mesh->texcoords && tri.ids[k].texcoordId >= mesh->texcoord_count)) {
+                            bad_index = true; return;
+                        }
+                    }
+                    V3 a = ld(mesh->points[tri.ids[0].vertexId]);
+                    V3 b = ld(mesh->points[tri.ids[1].vertexId]);
+                    V3 c = ld(mesh->points[tri.ids[2].vertexId]);
+                    V3 e1 = sub(b, a), e2 = sub(c, a);
+                    rt_dev_tri &dt = out.tris[tri0 + f];
+                    st(dt.a, a); st(dt.e1, e1); st(dt.e2, e2); st(dt.n, cross(e1, e2));
+                    rt_dev_attr &da = out.attrs[tri0 + f];
+                    std::memset(&da, 0, sizeof(da));
+                    if (mesh->normals) {
+                        st(da.n0, ld(mesh->normals[tri.ids[0].normalId]));
+                        st(da.n1, ld(mesh->normals[tri.ids[1].normalId]));
+                        st(da.n2, ld(mesh->normals[tri.ids[2].normalId]));
+                    }
+                    if (mesh->texcoords) {
+                        const rt_vec2f &t0 = mesh->texcoords[tri.ids[0].texcoordId];
+                        const rt_vec2f &t1 = mesh->texcoords[tri.ids[1].texcoordId];
+                        const rt_vec2f &t2 = mesh->texcoords[tri.ids[2].texcoordId];
+                        da.uv0[0] = t0.x; da.uv0[1] = t0.y; da.uv1[0] = t1.x; da.uv1[1] = t1.y;
+                        da.uv2[0] = t2.x; da.uv2[1] = t2.y;
                     }
                 }
-                V3 a = ld(mesh->points[tri.ids[0].vertexId]);
-                V3 b = ld(mesh->points[tri.ids[1].vertexId]);
-                V3 c = ld(mesh->points[tri.ids[2].vertexId]);
-                V3 e1 = sub(b, a), e2 = sub(c, a);
-                rt_dev_tri dt;
-                st(dt.a, a); st(dt.e1, e1); st(dt.e2, e2); st(dt.n, cross(e1, e2));
-                out.tris.push_back(dt);
-                rt_dev_attr da;
-                std::memset(&da, 0, sizeof(da));
-                if (mesh->normals) {
-                    st(da.n0, ld(mesh->normals[tri.ids[0].normalId]));
-                    st(da.n1, ld(mesh->normals[tri.ids[1].normalId]));
-                    st(da.n2, ld(mesh->normals[tri.ids[2].normalId]));
+            };
+            {
+                unsigned workers = mesh->face_count >= 16384u ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+                std::vector<std::thread> pool;
+                const uint32_t share = (mesh->face_count + workers - 1) / workers;
+                for (unsigned w = 1; w < workers; w++) {
+                    const uint32_t from = std::min(mesh->face_count, w * share), to = std::min(mesh->face_count, (w + 1) * share);
+                    try { pool.emplace_back(gather, from, to); } catch (...) { gather(from, to); }
                 }
-                if (mesh->texcoords) {
-                    const rt_vec2f &t0 = mesh->texcoords[tri.ids[0].texcoordId];
-                    const rt_vec2f &t1 = mesh->texcoords[tri.ids[1].texcoordId];
-                    const rt_vec2f &t2 = mesh->texcoords[tri.ids[2].texcoordId];
-                    da.uv0[0] = t0.x; da.uv0[1] = t0.y; da.uv1[0] = t1.x; da.uv1[1] = t1.y;
-                    da.uv2[0] = t2.x; da.uv2[1] = t2.y;
-                }
-                out.attrs.push_back(da);
+                gather(0, std::min(mesh->face_count, share));
+                for (auto &t : pool) t.join();
             }
+            if (bad_index) { out.error = "triangle with an index outside its attribute table"; return -2; }
 
             MeshWalk walk{mesh, out, dm.node_base};
             if (!walk.run(&dm.root_entry)) { out.error = walk.error; return -2; }

@@ -1203,6 +1203,8 @@ struct rt_gpu_scene {
     double kind_ms[RT_KINDS] = {0.0, 0.0, 0.0, 0.0};
     uint32_t launches = 0;
     uint64_t samples = 0;
+    double create_ms[2] = {0.0, 0.0};                         /* flatten, allocate + upload */
+    uint64_t resident_bytes = 0;
 };
 
 template <class T>
@@ -1330,8 +1332,10 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
     if (!scene || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_scene_create: NULL argument");
     *out = nullptr;
     if (rt_gpu_device_count() <= 0) return fail(RT_GPU_ERR_NO_DEVICE, "no HIP device is visible");
+    const auto t_begin = std::chrono::steady_clock::now();
     rt_flat_scene flat;
     if (rt_flatten_scene(scene, flat) != 0) return fail(RT_GPU_ERR_SCENE, "scene rejected: " + flat.error);
+    const auto t_flat = std::chrono::steady_clock::now();
 
     /* a parked path record keeps the instance to walk and the light being sampled in 16 bits each */
     if (flat.instances.size() > 0xFFFEu) return fail(RT_GPU_ERR_SCENE, "scene rejected: more than 65534 mesh instances");
@@ -1427,7 +1431,26 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
         s->d_aes_table = const_cast<uint32_t *>(tb);
     } while (0);
     if (rc) { rt_gpu_scene_destroy(s); return rc; }
+    (void)hipDeviceSynchronize();
+    const auto t_end = std::chrono::steady_clock::now();
+    s->create_ms[0] = std::chrono::duration<double, std::milli>(t_flat - t_begin).count();
+    s->create_ms[1] = std::chrono::duration<double, std::milli>(t_end - t_flat).count();
+    s->resident_bytes = sizeof(rt_dev_node) * flat.nodes.size() + sizeof(rt_dev_tri) * flat.tris.size() + sizeof(rt_dev_attr) * flat.attrs.size() +
+                        sizeof(float) * flat.texels.size();
     *out = s;
+    return RT_GPU_OK;
+}
+
+int rt_gpu_scene_info(const rt_gpu_scene *s, rt_gpu_scene_info_t *out)
+{
+    if (!s || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_scene_info: NULL argument");
+    memset(out, 0, sizeof(*out));
+    out->flatten_ms = s->create_ms[0]; out->upload_ms = s->create_ms[1];
+    out->resident_bytes = s->resident_bytes;
+    out->mesh_count = (uint32_t)s->dev.mesh_count; out->instance_count = (uint32_t)s->dev.instance_count;
+    out->texture_count = (uint32_t)s->dev.texture_count; out->stack_levels = s->dev.stack_cap;
+    for (uint32_t i = 0; i < s->knobs.lanes; i++)
+        out->work_bytes += s->lanes[i].sample_bytes + 2 * s->lanes[i].parked_records * RT_RECORD_WORDS * 4;
     return RT_GPU_OK;
 }
 

@@ -12,6 +12,7 @@
  */
 #include <float.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -20,6 +21,8 @@
 #define LEAF_MAX_TRIANGLES 16u      /* src/main.c:120 */
 #define SPLIT_RETRY_LIMIT 200       /* the reference retries forever on coincident centroids */
 #define TREE_DEPTH_LIMIT 4096u      /* the reference recurses without bound; no real model comes near (the dog: 24 levels) */
+#define FORK_LEVELS 3u              /* the two subtrees of a node at depth <= 3 are built by two threads (8 at most) */
+#define FORK_MIN_TRIANGLES 4096u    /* ... when the node is large enough to be worth a thread */
 
 typedef struct node_pool { rt_mesh_node *nodes; size_t used, cap; } node_pool;
 
@@ -29,9 +32,23 @@ static inline float axis_of(const rt_vec3f *v, int axis) { return (&v->x)[axis];
 
 /* bounds of the node's triangle range, then split on the midpoint of the
  * longest axis by centroid; src/main.c:92-175 */
+static void build_node(rt_mesh_node *node, rt_mesh *mesh, uint32_t depth, node_pool *pool);
+
+typedef struct subtree_job { rt_mesh_node *node; rt_mesh *mesh; uint32_t depth; node_pool *pool; } subtree_job;
+static void *subtree_thread(void *arg)
+{
+    subtree_job *job = arg;
+    build_node(job->node, job->mesh, job->depth, job->pool);
+    return NULL;
+}
+
+/* The two subtrees of a node work on disjoint ranges of the face table, so they can be built side by side:
+ * the same boxes, the same swaps in the same order within each range, hence the same tree and the same face
+ * permutation as the sequential recursion (only the children's addresses in the pool differ). */
 static void build_node(rt_mesh_node *node, rt_mesh *mesh, uint32_t depth, node_pool *pool)
 {
-    if (depth > mesh->tree_depth) mesh->tree_depth = depth;
+    uint32_t seen = __atomic_load_n(&mesh->tree_depth, __ATOMIC_RELAXED);
+    while (depth > seen && !__atomic_compare_exchange_n(&mesh->tree_depth, &seen, depth, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
 
     rt_bbox box = { { FLT_MAX, FLT_MAX, FLT_MAX }, { -FLT_MAX, -FLT_MAX, -FLT_MAX } };
     for (uint32_t i = node->first_triangle_id; i <= node->last_triangle_id; i++) {
@@ -79,14 +96,18 @@ static void build_node(rt_mesh_node *node, rt_mesh *mesh, uint32_t depth, node_p
         if (++tries > SPLIT_RETRY_LIMIT) return;   /* unsplittable: keep it a (large) leaf */
     }
 
-    rt_mesh_node *pair = pool->nodes + pool->used;
-    pool->used += 2;
+    rt_mesh_node *pair = pool->nodes + __atomic_fetch_add(&pool->used, 2, __ATOMIC_RELAXED);
     memset(pair, 0, 2 * sizeof(*pair));
     node->childs = pair;
     pair[0].first_triangle_id = first;  pair[0].last_triangle_id = pivot - 1;
     pair[1].first_triangle_id = pivot;  pair[1].last_triangle_id = last;
-    build_node(pair + 0, mesh, depth + 1, pool);
+    pthread_t helper;
+    subtree_job job = { pair + 0, mesh, depth + 1, pool };
+    int forked = depth <= FORK_LEVELS && last - first + 1 >= FORK_MIN_TRIANGLES &&
+                 pthread_create(&helper, NULL, subtree_thread, &job) == 0;
+    if (!forked) build_node(pair + 0, mesh, depth + 1, pool);
     build_node(pair + 1, mesh, depth + 1, pool);
+    if (forked) pthread_join(helper, NULL);
 }
 
 int rt_host_mesh_build_tree(rt_mesh *mesh)

@@ -22,7 +22,7 @@ KERNEL_KINDS = ("new_paths", "resumed_paths", "tree", "finish")
 
 EXPORTS = [
     "rt_gpu_device_count", "rt_gpu_last_error", "rt_gpu_scene_create", "rt_gpu_scene_destroy",
-    "rt_gpu_scene_set_camera", "rt_gpu_render_region", "rt_gpu_render_region_device", "rt_gpu_render_region_static",
+    "rt_gpu_scene_set_camera", "rt_gpu_scene_info", "rt_gpu_render_region", "rt_gpu_render_region_device", "rt_gpu_render_region_static",
     "rt_gpu_normalize_device", "rt_gpu_render_jobs", "rt_gpu_find_ray_hit", "rt_gpu_find_ray_hit_serial", "rt_gpu_quantize", "rt_gpu_quantize_device",
     "rt_gpu_multi_create", "rt_gpu_multi_destroy", "rt_gpu_multi_device_count", "rt_gpu_multi_render_frame",
     "rt_gpu_multi_rows_per_rank", "rt_gpu_assemble_bands_device",
@@ -54,6 +54,11 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
 
 
+class SceneInfo(C.Structure):
+    _fields_ = [("flatten_ms", C.c_double), ("upload_ms", C.c_double), ("resident_bytes", C.c_uint64), ("work_bytes", C.c_uint64),
+                ("mesh_count", C.c_uint32), ("instance_count", C.c_uint32), ("texture_count", C.c_uint32), ("stack_levels", C.c_uint32)]
+
+
 class GpuError(RuntimeError):
     pass
 
@@ -81,6 +86,7 @@ def lib():
         L.rt_gpu_scene_destroy.argtypes = [C.c_void_p]
         L.rt_gpu_scene_destroy.restype = None
         L.rt_gpu_scene_set_camera.argtypes = [C.c_void_p, C.POINTER(T.Camera)]
+        L.rt_gpu_scene_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
         L.rt_gpu_render_region.argtypes = [C.c_void_p, C.POINTER(T.Image3f), T.Rect2u, C.c_uint32,
                                            C.c_uint64, C.POINTER(Options)]
         L.rt_gpu_render_region_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, T.Rect2u,
@@ -138,6 +144,11 @@ class GpuScene:
             self.close()
         except Exception:
             pass
+
+    def info(self):
+        out = SceneInfo()
+        _check(lib().rt_gpu_scene_info(self._h, C.byref(out)))
+        return {n: getattr(out, n) for n, _ in out._fields_}
 
     def render_region(self, image, region, spp, seed, options=None):
         """rt_gpu_render_region: host image in, host image out."""
