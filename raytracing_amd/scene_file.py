@@ -6,7 +6,8 @@ lights, mesh instances and the camera are C initialisers.  This is the same data
     {"name": "...",
      "camera": {"position": [x,y,z], "look_at": [x,y,z], "up": [x,y,z], "fov_degrees": 60},
      "materials": [{"diffuse": [r,g,b]} | {"mirror": [r,g,b]} | {"glass": 1.5} |
-                   {"diffuse": [r,g,b], "texture": "name"}],
+                   {"diffuse": [r,g,b], "texture": "name"} |
+                   {"mtl": "file.mtl", "name": "newmtl name"}],     the model's own material library
      "spheres":   [{"center": [x,y,z], "radius": r, "material": i}],
      "planes":    [{"normal": [x,y,z], "d": d, "material": i}],
      "lights":    [{"center": [x,y,z], "radius": r, "color": [r,g,b], "albedo": a}],
@@ -14,6 +15,11 @@ lights, mesh instances and the camera are C initialisers.  This is the same data
      "meshes":    {"name": "file.npz"},          parsed OBJ arrays (see host.mesh_from_obj_arrays)
      "instances": [{"mesh": "name", "position": [x,y,z], "material": i, "mirrored_x": false}]}
 
+An "mtl" material takes its data from a Wavefront material library, the data the OBJ parser of the
+reference already reads and the reference then ignores (src/fast_obj.h:49-77: Kd, Ni, d, map_Kd):
+diffuse colour = Kd; dissolve d < 1 makes it glass with refraction index Ni; map_Kd names the
+diffuse map, looked up among the document's textures by file name without extension (the decoded
+pixels come from the document's "textures" files: decoding images stays with the host program).
 File names are relative to the document.  Numbers become C floats exactly as the C initialisers
 would (a decimal literal rounded to float); "fov_degrees" goes through the reference's own
 expression (src/main.c:1037), "fov" gives radians directly.  Nothing here renders: the result is a
@@ -44,7 +50,57 @@ def _index(v, count, what):
     return v
 
 
-def _material(m, textures, where):
+def parse_mtl(text):
+    """Wavefront .mtl text -> {material name: {"Kd": (r,g,b), "Ni": n, "d": alpha, "map_Kd": file, ...}}
+    with the defaults of the reference's parser (src/fast_obj.h:mtl_default: Kd 1, Ni 1, d 1)."""
+    out, cur = {}, None
+    for raw in text.splitlines():
+        line = raw.split("#", 1)[0].split()
+        if not line:
+            continue
+        key, args = line[0], line[1:]
+        if key == "newmtl":
+            cur = out.setdefault(" ".join(args), {"Kd": (1.0, 1.0, 1.0), "Ni": 1.0, "d": 1.0})
+        elif cur is None:
+            continue
+        elif key in ("Ka", "Kd", "Ks", "Ke", "Tf") and len(args) >= 3:
+            cur[key] = tuple(float(x) for x in args[:3])
+        elif key in ("Ns", "Ni", "d") and args:
+            cur[key] = float(args[0])
+        elif key == "Tr" and args:                       # the parser reads Tr as 1 - d
+            cur["d"] = 1.0 - float(args[0])
+        elif key == "illum" and args:
+            cur[key] = int(float(args[0]))
+        elif key.startswith("map_") or key == "bump":
+            cur["map_bump" if key == "bump" else key] = args[-1] if args else ""
+    return out
+
+
+def _material_from_mtl(m, textures, base, where):
+    path = os.path.join(base, m["mtl"])
+    try:
+        with open(path) as f:
+            library = parse_mtl(f.read())
+    except OSError as e:
+        raise SceneFileError(f"{where}: cannot read {path}: {e}")
+    name = m.get("name") or (next(iter(library)) if len(library) == 1 else None)
+    if name not in library:
+        raise SceneFileError(f"{where}: material {name!r} is not in {m['mtl']} (it has {sorted(library)})")
+    entry = library[name]
+    if entry["d"] < 1.0:
+        return scenes._material(transparent=True, n=float(entry["Ni"]))
+    tex = None
+    if entry.get("map_Kd"):
+        stem = os.path.splitext(os.path.basename(entry["map_Kd"].replace("\\", "/")))[0]
+        if stem not in textures:
+            raise SceneFileError(f"{where}: map_Kd {entry['map_Kd']!r} needs a texture named {stem!r} in the document")
+        tex = textures[stem]
+    return scenes._material(diffuse=entry["Kd"], texture=tex)
+
+
+def _material(m, textures, where, base="."):
+    if "mtl" in m:
+        return _material_from_mtl(m, textures, base, where)
     kinds = [k for k in ("diffuse", "mirror", "glass") if k in m]
     if len(kinds) != 1:
         raise SceneFileError(f"{where}: exactly one of diffuse / mirror / glass, got {sorted(m)}")
@@ -91,7 +147,7 @@ def load(source, base_dir=None):
     camera = T.Camera(_vec(cam["position"], "camera.position"), _vec(cam["look_at"], "camera.look_at"),
                       _vec(cam["up"], "camera.up"), fov)
 
-    mats = [_material(m, textures, f"materials[{i}]") for i, m in enumerate(doc.get("materials", []))]
+    mats = [_material(m, textures, f"materials[{i}]", base) for i, m in enumerate(doc.get("materials", []))]
     n_mat = len(mats)
     spheres = [T.Sphere(_vec(s["center"], f"spheres[{i}].center"), float(s["radius"]),
                         _index(s["material"], n_mat, f"spheres[{i}]"))

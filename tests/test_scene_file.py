@@ -76,3 +76,43 @@ def test_fov_in_degrees_is_the_reference_expression():
 def test_malformed_documents_are_refused(doc):
     with pytest.raises(scene_file.SceneFileError):
         scene_file.load(doc)
+
+
+MTL = """# exporter header
+newmtl Dog
+\tNs 10.0000
+\tNi 1.5000
+\td 1.0000
+\tTr 0.0000
+\tKd 0.8000 0.7000 0.6000
+\tmap_Kd textures\\dog_texture_rgb8.jpg
+\tmap_bump dog_bump.jpg
+newmtl Crystal
+\tNi 1.3300
+\tTr 0.7500
+"""
+
+
+def test_materials_from_a_model_material_library(tmp_path):
+    """The .mtl data the reference's OBJ parser reads and the reference never uses (src/fast_obj.h:49-77):
+    Kd becomes the diffuse colour, map_Kd the diffuse map (by file stem among the document's textures),
+    a dissolve below 1 glass with refraction index Ni."""
+    (tmp_path / "model.mtl").write_text(MTL)
+    lib = scene_file.parse_mtl(MTL)
+    assert lib["Dog"]["Kd"] == (0.8, 0.7, 0.6) and lib["Dog"]["Ni"] == 1.5 and lib["Dog"]["d"] == 1.0
+    assert lib["Crystal"]["d"] == 0.25 and lib["Dog"]["map_bump"] == "dog_bump.jpg"
+    import shutil
+    shutil.copy(os.path.join(scenes.ASSET_DIR, "dog_texture_rgb8.npz"), tmp_path / "dog_texture_rgb8.npz")
+    doc = {"camera": {"position": [0, 10, 85], "look_at": [0, 0, 0], "up": [0, 1, 0], "fov_degrees": 60},
+           "textures": {"dog_texture_rgb8": "dog_texture_rgb8.npz"},
+           "materials": [{"mtl": "model.mtl", "name": "Dog"}, {"mtl": "model.mtl", "name": "Crystal"}],
+           "spheres": [{"center": [0, 0, 0], "radius": 5, "material": 0}, {"center": [9, 0, 0], "radius": 3, "material": 1}]}
+    sh = scene_file.load(doc, base_dir=str(tmp_path))
+    m0, m1 = sh.scene.materials[0], sh.scene.materials[1]
+    assert m0.textured and not m0.transparent and np.allclose(m0.diffuse_color.tuple(), (0.8, 0.7, 0.6))
+    assert m0.texture.contents.size.x == 1024
+    assert m1.transparent and abs(m1.n - 1.33) < 1e-6 and not m1.textured
+    with pytest.raises(scene_file.SceneFileError, match="not in model.mtl"):
+        scene_file.load(dict(doc, materials=[{"mtl": "model.mtl", "name": "Cat"}]), base_dir=str(tmp_path))
+    with pytest.raises(scene_file.SceneFileError, match="needs a texture"):
+        scene_file.load(dict(doc, textures={}), base_dir=str(tmp_path))
