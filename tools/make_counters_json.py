@@ -13,7 +13,7 @@ tag, workload, paths = sys.argv[1], sys.argv[2], sys.argv[3:]
 
 def kind_of(name):
     key = name.split("(")[0].replace("void ", "")
-    if "<" not in key:
+    if not key.startswith("rt_") or "<" not in key or ">" not in key:
         return None
     args = [a.strip() for a in key[key.index("<") + 1:key.rindex(">")].split(",")]
     if key.startswith("rt_shade_kernel"):
@@ -59,7 +59,7 @@ for k, c in sums.items():
 json.dump({
     "workload": workload,
     "frames_averaged": frames,
-    "source": f"profiles/{tag}_pmc_*.csv: rocprofv3 --pmc, one pass per counter group, of `python3 bench.py --steps 1 --warmup 0 "
+    "source": f"profiles/{tag}_pmc_*.csv.gz (raw) and .txt (per-kernel sums): rocprofv3 --pmc, one pass per counter group, of `python3 bench.py --steps 1 --warmup 0 "
               "--no-cpu-baseline --frames-in-flight 1`; per frame and kind of launch; FETCH_SIZE and WRITE_SIZE in KiB x 1024, raw "
               "(the read counter tallies 128-byte requests at 64 bytes on gfx950: bench.py doubles it)",
     "kinds": kinds,
