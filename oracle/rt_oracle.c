@@ -17,7 +17,7 @@
  * the order the reference's source performs it (doubles appear exactly where
  * the reference's C promotes to double).  Build with -ffp-contract=off
  * (oracle/Makefile does) and the result is bit-identical to the reference
- * compiled from its own sources with the same flag: tests/test_oracle_vs_ref.py
+ * compiled from its own sources with the same flag: tests/test_oracle_vs_reference_live.py
  * checks that on whole float buffers, and tests/golden/ holds the vectors for
  * machines that do not have the reference.
  *
