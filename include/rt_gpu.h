@@ -96,10 +96,12 @@ typedef struct rt_gpu_stats {
     double   fresh_ms;           /* part of shade_ms spent in the launches that start new paths (first of each batch) */
     double   finish_ms;          /* rt_finish_kernel (last paths of a batch), not part of shade_ms or tree_ms */
     uint64_t rounds;         /* shade launches that had work, summed over batches (the first of a batch included) */
-    uint64_t overflowed;     /* paths that found the parked list full (the lists hold every path of a batch, so 0;
-                              * if not, rt_gpu_get_stats fails) */
+    uint64_t overflowed;     /* paths that found the parked list full (the lists hold every path of a batch, or the
+                              * batch's paths start in several passes, so 0; if not, rt_gpu_get_stats fails) */
     uint32_t launches;       /* render calls x sample batches */
-    uint32_t reserved;
+    uint32_t passes;         /* launch sequences enqueued for those batches by rt_gpu_render_region_device: one per batch
+                              * when the lists of paths in transit hold every path of the batch, up to 8 when the memory
+                              * budgets or the device leave them smaller (the new paths of a batch then start in turns) */
 } rt_gpu_stats;
 
 /* Library / device ------------------------------------------------------- */

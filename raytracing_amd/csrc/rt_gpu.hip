@@ -101,10 +101,10 @@ __device__ __forceinline__ void flush_counters(const rt::Counters &cn, uint64_t 
  * own cursors in the same record, so no launch needs a value from the host: the host enqueues a fixed
  * sequence of launches and the ones with nothing to do return at once. */
 struct QueueCounters {
-    uint32_t unit_next;              /* new paths: next portion of fresh work */
+    uint32_t unit_next;              /* new paths: next portion of fresh work (the batch's cursor lives in its first record) */
     uint32_t in_next;                /* cursor of whoever carries this round's records on (resumed-path or finishing launch) */
     uint32_t out_reserved;           /* slots reserved in this round's output list */
-    uint32_t overflow;               /* paths that found the output list full (cannot happen: the lists hold every path) */
+    uint32_t overflow;               /* paths that found the output list full (cannot happen: see ShadeParams.out_limit) */
     uint32_t parked;                 /* records actually parked (out_reserved counts whole chunks) */
     uint32_t tree_next;              /* cursor of the tree launch that answers this round's records */
     uint32_t pad[2];
@@ -119,6 +119,10 @@ struct ShadeParams {
     const uint32_t *in_list;         /* resume: records parked by the previous round (answered) */
     uint32_t *out_list;              /* records this launch parks */
     uint32_t out_capacity;           /* slots of either list */
+    uint32_t *portion_next;          /* new paths: the batch's cursor over its portions of fresh work (shared by the passes of the batch) */
+    uint32_t out_limit;              /* new paths, lists smaller than the batch: a wave takes no further portion once it has seen this many
+                                      * slots reserved (a reservation returns the count of all waves; what the waves hold and take until
+                                      * they reserve again still fits); the portions left wait for the next pass.  0: no limit */
     uint32_t finish_below;           /* resume: the round runs only if more records than this were parked (else the finishing launch takes them) */
     uint32_t chunk;                  /* new paths: output slots a wave reserves per atomic (<= RT_CHUNK, multiple of 64) */
     uint32_t tail_lanes;             /* a wave left with fewer paths than this and no input hands them to the next round (0: never) */
@@ -188,6 +192,8 @@ rt_shade_kernel(const ShadeParams P)
         if (blockIdx.x >= (in_slots + 255u) / 256u) return;
         /* few records per wave: reserve output slots in smaller chunks (less padding for the next launch to skip) */
         chunk = records >= (4u << 20) ? RT_CHUNK : RT_SMALL_CHUNK;
+    } else if (__builtin_amdgcn_readfirstlane(*P.portion_next) >= P.blocks_x * P.block_rows * ((P.launch_spp + RT_PORTION_SPP - 1u) / RT_PORTION_SPP)) {
+        return;                                          /* an earlier pass started every path of the batch */
     }
     rt::Stack stk; stk.base = nullptr; stk.stride = 0;                      /* this kernel walks no tree */
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
@@ -258,6 +264,7 @@ rt_shade_kernel(const ShadeParams P)
     };
     if (!FRESH) { stage_issue(); stage_land(); stage_issue(); }
     uint32_t out_cur = 0, out_end = 0;                  /* reserved output range */
+    uint32_t seen_reserved = 0;                         /* slots of the list reserved by all waves, as of this wave's latest reservation */
     uint32_t parked_here = 0;
 
     /* write the paths of the lanes that `want` it to the parked list (m: the machine holding them) */
@@ -272,6 +279,7 @@ rt_shade_kernel(const ShadeParams P)
             uint32_t v = 0;
             if (lane == 0) v = atomicAdd(&P.q->out_reserved, chunk);
             next_base = __builtin_amdgcn_readfirstlane(v);
+            seen_reserved = next_base + chunk;
         }
         if (want) {
             uint32_t slot = rank < room ? out_cur + rank : next_base + (rank - room);
@@ -298,8 +306,12 @@ rt_shade_kernel(const ShadeParams P)
     uint4 *pool = reinterpret_cast<uint4 *>(lds) + (threadIdx.x >> 6) * (3u * RT_POOL);
     auto camera_step = [&]() {
         if (item_next >= unit_items) {                   /* next portion */
+            if (P.out_limit && seen_reserved > P.out_limit) {
+                input_done = true;                       /* the list is nearly full: the rest of the batch is another pass's */
+                return;
+            }
             uint32_t u = 0;
-            if (lane == 0) u = atomicAdd(&P.q->unit_next, 1u);
+            if (lane == 0) u = atomicAdd(P.portion_next, 1u);
             u = __builtin_amdgcn_readfirstlane(u);
             if (u >= units * parts) { input_done = true; return; }
             unit = u / parts;
@@ -1163,6 +1175,7 @@ static int static_scratch_of(int device, unsigned char **out)
 #define RT_KINDS 4                    /* detailed counters are kept per kind of launch: */
 enum { KIND_FRESH = 0, KIND_RESUME = 1, KIND_TREE = 2, KIND_FINISH = 3 };
 #define RT_MAX_LANES 8
+#define RT_MAX_PASSES 8               /* passes over a batch whose parked lists are smaller than the batch */
 
 /* Work memory of one batch of samples in flight: a frame's batches go round-robin over the lanes,
  * each on its own stream, so the latency-bound last rounds of one batch run beside the
@@ -1171,7 +1184,7 @@ struct BatchLane {
     hipStream_t stream = nullptr;
     float *d_samples = nullptr; uint64_t sample_bytes = 0;     /* per-sample values between shading and the per-pixel sum */
     uint32_t *d_parked[2] = {nullptr, nullptr}; uint64_t parked_records = 0;   /* paths in transit, ping-pong */
-    QueueCounters *d_rounds = nullptr;                         /* one record per round */
+    QueueCounters *d_rounds = nullptr;                         /* one record per round of each pass */
     hipEvent_t done = nullptr;                                 /* after the lane's latest per-pixel sum */
 };
 
@@ -1201,7 +1214,7 @@ struct rt_gpu_scene {
     std::vector<Timer> timers;                                /* pending kernel timings */
     std::vector<hipEvent_t> spare_events;
     double kind_ms[RT_KINDS] = {0.0, 0.0, 0.0, 0.0};
-    uint32_t launches = 0;
+    uint32_t launches = 0, passes = 0;
     uint64_t samples = 0;
     double create_ms[2] = {0.0, 0.0};                         /* flatten, allocate + upload */
     uint64_t resident_bytes = 0;
@@ -1416,7 +1429,7 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
                 BatchLane &L = s->lanes[i];
                 ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess &&
                      hipEventCreateWithFlags(&L.done, hipEventDisableTiming) == hipSuccess &&
-                     hipMalloc(reinterpret_cast<void **>(&L.d_rounds), sizeof(QueueCounters) * (s->knobs.max_rounds + 1)) == hipSuccess;
+                     hipMalloc(reinterpret_cast<void **>(&L.d_rounds), sizeof(QueueCounters) * (s->knobs.max_rounds + 1) * RT_MAX_PASSES) == hipSuccess;
             }
             if (!ok) { rc = fail(RT_GPU_ERR_DEVICE, "could not create the streams, events and round records of the batch lanes"); break; }
         }
@@ -1616,12 +1629,18 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     R.norm = rt_pixel_norm((o && o->spp_total) ? o->spp_total : spp);
 
     /* The call's samples are rendered in batches (whole samples per pixel of the region; whole frames when
-     * the call makes several).  A batch needs 12 bytes per path for the sample values and two lists
-     * of 192 bytes per path (+ one partly used chunk per wave): every path of the batch can be parked
-     * at once, so parking cannot fail.  Batches go round-robin over the lanes: the budgets are shared
-     * between the lanes in use. */
+     * the call makes several).  A batch needs 12 bytes per path for the sample values and two lists of
+     * 192-byte records for the paths in transit between launches.  Lists that hold every path of the batch
+     * (+ one partly used chunk per wave) cannot fill up; where the budgets or the device do not allow
+     * that, the lists get what is allowed and the batch's paths start in several passes: the launch that
+     * starts paths stops taking portions of new work when its list is nearly full, the rounds carry those
+     * paths to their end, and the next pass goes on with the portions left (on the device: the host
+     * enqueues the passes a batch can need at worst, and passes without work return at once).  Only when
+     * that would take more than RT_MAX_PASSES passes the batches get smaller.  Batches go round-robin
+     * over the lanes: the budgets are shared between the lanes in use. */
     const uint64_t units = (uint64_t)G.blocks_x * G.block_rows;
     const uint64_t items_per_sample = units * 64;
+    const uint64_t record_bytes = (uint64_t)RT_RECORD_WORDS * 4;
     uint64_t batch_spp = (K.batch_paths + items_per_sample / 2) / items_per_sample;
     if (batch_spp < 1) batch_spp = 1;
     if (batch_spp > total_spp) batch_spp = total_spp;
@@ -1630,9 +1649,9 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     size_t free_bytes = 0, device_bytes = 0;
     if (hipMemGetInfo(&free_bytes, &device_bytes) != hipSuccess) { (void)hipGetLastError(); free_bytes = ~(size_t)0; }
     uint64_t held = 0;
-    for (uint32_t i = 0; i < K.lanes; i++) held += s->lanes[i].sample_bytes + 2 * s->lanes[i].parked_records * RT_RECORD_WORDS * 4;
-    uint32_t shade_grid = 0, lanes_used = 0, lane_cap = K.lanes;
-    uint64_t batches = 0, capacity = 0, chunk_slack = 0;
+    for (uint32_t i = 0; i < K.lanes; i++) held += s->lanes[i].sample_bytes + 2 * s->lanes[i].parked_records * record_bytes;
+    uint32_t shade_grid = 0, resume_grid = 0, lanes_used = 0, lane_cap = K.lanes, passes = 1;
+    uint64_t batches = 0, capacity = 0, out_limit = 0;
     (void)device_bytes;
     for (;;) {
         if (frames > 1) {
@@ -1654,32 +1673,57 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
             batch_spp = (total_spp + batches - 1) / batches;        /* batches of equal size */
         }
         lanes_used = (uint32_t)(batches < lane_cap ? batches : lane_cap);
-        /* no more workgroups than there are portions of fresh work for their waves (small regions) */
+        /* no more workgroups than there are portions of fresh work for their waves (small regions); the
+         * resumed-path launches get no more workgroups than the first launch */
         const uint64_t portions_max = units * ((batch_spp + RT_PORTION_SPP - 1) / RT_PORTION_SPP);
         shade_grid = s->shade_blocks;
         if ((portions_max + 3) / 4 < shade_grid) shade_grid = (uint32_t)((portions_max + 3) / 4);
-        /* every wave of a launch leaves at most one reserved chunk partly used; the resumed-path launches get
-         * no more workgroups than the first launch */
-        chunk_slack = (uint64_t)shade_grid * (RT_BLOCK / 64) * RT_CHUNK;
-        capacity = (batch_spp * items_per_sample + chunk_slack + RT_CHUNK - 1) / RT_CHUNK * RT_CHUNK;
-        const uint64_t sample_bytes = batch_spp * items_per_sample * 12, list_bytes = capacity * RT_RECORD_WORDS * 4;
-        /* the budgets are the handle's: a lane gets its share whether or not the other lanes are in use */
-        const bool fits_budget = sample_bytes * lane_cap <= (K.scratch_mb << 20) && 2 * list_bytes * lane_cap <= (K.parked_mb << 20) &&
-                                 capacity <= 0xFFFFFF00ull;
-        /* what the lanes already hold is freed before they grow, so it counts as available */
-        const bool fits_device = free_bytes == ~(size_t)0 ||
-                                 (double)((sample_bytes + 2 * list_bytes) * lanes_used) <= 0.9 * ((double)free_bytes + (double)held);
-        bool ok = fits_budget && fits_device;
+        resume_grid = s->resume_blocks < shade_grid ? s->resume_blocks : shade_grid;
+        const uint64_t batch_paths = batch_spp * items_per_sample;
+        const uint64_t shade_waves = (uint64_t)shade_grid * (RT_BLOCK / 64), resume_waves = (uint64_t)resume_grid * (RT_BLOCK / 64);
+        /* every wave of a launch leaves at most one reserved chunk partly used */
+        const uint64_t full = (batch_paths + shade_waves * RT_CHUNK + RT_CHUNK - 1) / RT_CHUNK * RT_CHUNK;
+        const uint64_t sample_bytes = batch_paths * 12;
+        /* the budgets are the handle's: a lane gets its share whether or not the other lanes are in use;
+         * what the lanes already hold is freed before they grow, so it counts as available on the device */
+        uint64_t lists_bytes = (K.parked_mb << 20) / lane_cap;
+        bool ok = sample_bytes * lane_cap <= (K.scratch_mb << 20);
+        const bool within_budget = ok;
+        if (free_bytes != ~(size_t)0) {
+            const double per_lane = 0.9 * ((double)free_bytes + (double)held) / (double)lanes_used - (double)sample_bytes;
+            if (per_lane <= 0.0) { ok = false; lists_bytes = 0; }
+            else if (per_lane < (double)lists_bytes) lists_bytes = (uint64_t)per_lane;
+        }
+        uint64_t allowed = lists_bytes / (2 * record_bytes) / RT_CHUNK * RT_CHUNK;       /* slots of either list */
+        if (allowed > 0xFFFFFF00ull) allowed = 0xFFFFFF00ull;
+        capacity = full; passes = 1; out_limit = 0;
+        if (ok && full > allowed) {
+            /* a wave learns how full the list is when it reserves a chunk of it.  Once the limit is passed a wave
+             * can still fill the chunk it has, take one more portion of new paths, park all of them and the paths
+             * its lanes and its pool hold (the first of these reservations tells it to stop), and leave a chunk
+             * partly used; the resumed-path launches park no more records than they were given, plus a partly
+             * used chunk per wave */
+            const uint64_t after_look = shade_waves * (RT_CHUNK + 64u * RT_PORTION_SPP + 64u + RT_POOL + RT_CHUNK);
+            const uint64_t margin = after_look + resume_waves * RT_CHUNK;
+            const uint64_t padding = shade_waves * RT_CHUNK;             /* reserved slots that hold no record */
+            capacity = allowed;
+            if (capacity > margin + 2 * padding) {
+                out_limit = capacity - margin;
+                const uint64_t started_per_pass = out_limit - padding;   /* a pass ends early only with this many paths parked */
+                const uint64_t needed = (batch_paths + started_per_pass - 1) / started_per_pass;
+                if (needed <= RT_MAX_PASSES) passes = (uint32_t)needed; else ok = false;
+            } else ok = false;
+        }
         for (uint32_t i = 0; ok && i < lanes_used; i++) ok = ensure_lane(s->lanes[(first_lane + i) % K.lanes], sample_bytes, capacity);
         if (ok) break;
         if (batch_spp == 1 || (frames > 1 && batch_spp == spp)) {
             if (lane_cap > 1) { lane_cap--; continue; }              /* the smallest batches: fewer of them in flight */
             if (frames > 1) { batch_spp = spp - 1; continue; }       /* fall back to one frame after the other */
-            if (!fits_budget)
+            if (!within_budget || (K.parked_mb << 20) / (2 * record_bytes) < full)
                 return fail(RT_GPU_ERR_MEMORY, "RT_GPU_SCRATCH_MB / RT_GPU_PARKED_MB are too small for one sample per pixel of this region (" +
-                            std::to_string((sample_bytes * lane_cap) >> 20) + " + " + std::to_string((2 * list_bytes * lane_cap) >> 20) + " MiB needed)");
+                            std::to_string(sample_bytes >> 20) + " + " + std::to_string((2 * full * record_bytes) >> 20) + " MiB would hold it)");
             return fail(RT_GPU_ERR_MEMORY, "the device has no room for the work memory of one sample per pixel of this region (" +
-                        std::to_string(((sample_bytes + 2 * list_bytes) * lanes_used) >> 20) + " MiB)");
+                        std::to_string((sample_bytes + 2 * full * record_bytes) >> 20) + " MiB)");
         }
         batch_spp = frames > 1 ? (batch_spp / spp + 1) / 2 * spp : (batch_spp + 1) / 2;      /* smaller batches and try again */
     }
@@ -1697,8 +1741,8 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     P.tail_lanes = finish_below == 0 ? 0 : K.tail_lanes;
     P.finish_below = finish_below;
     P.out_capacity = (uint32_t)capacity;
+    P.out_limit = (uint32_t)out_limit;
     const uint32_t rounds = K.max_rounds;
-    const uint32_t resume_grid = s->resume_blocks < shade_grid ? s->resume_blocks : shade_grid;
 
     RT_HIP(hipEventRecord(s->ev_start, caller));
     hipEvent_t previous_sum = nullptr;                   /* per-pixel sums run in batch order: a pixel's samples are added in sample order */
@@ -1711,37 +1755,41 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
         P.first_sample = first;
         P.launch_spp = (uint32_t)(total_spp - first64 < batch_spp ? total_spp - first64 : batch_spp);
         P.samples = L.d_samples;
-        RT_HIP(hipMemsetAsync(L.d_rounds, 0, sizeof(QueueCounters) * (rounds + 1), stream));
-        /* round 0: new paths */
-        P.stats = s->d_stats + KIND_FRESH * RT_STAT_WORDS;
-        P.q = L.d_rounds; P.q_in = nullptr; P.in_list = nullptr; P.out_list = L.d_parked[0];
-        P.chunk = RT_CHUNK;
-        if ((rc = timed_launch(s, timed, KIND_FRESH, stream, [&]() { launch_shade(true, detailed, s->specular, shade_grid, stream, P); }))) return rc;
-        /* rounds 1 ...: answer the parked queries, resume those paths.  What a round has to do stands in
-         * the previous round's record; launches of rounds that are not needed return at once. */
-        for (uint32_t r = 1; r <= rounds; r++) {
-            TreeParams T;
-            memset(&T, 0, sizeof(T));
-            T.S = P.S; T.list = L.d_parked[(r - 1) & 1]; T.capacity = P.out_capacity; T.finish_below = finish_below;
-            T.q = L.d_rounds + (r - 1); T.stats = s->d_stats + KIND_TREE * RT_STAT_WORDS;
-            if ((rc = timed_launch(s, timed, KIND_TREE, stream, [&]() {
-                    if (detailed) hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(s->tree_blocks), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, stream, T);
-                    else hipLaunchKernelGGL(rt_tree_kernel<false>, dim3(s->tree_blocks), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, stream, T);
-                }))) return rc;
-            P.stats = s->d_stats + KIND_RESUME * RT_STAT_WORDS;
-            P.q_in = L.d_rounds + (r - 1); P.q = L.d_rounds + r;
-            P.in_list = L.d_parked[(r - 1) & 1]; P.out_list = L.d_parked[r & 1];
-            if ((rc = timed_launch(s, timed, KIND_RESUME, stream, [&]() { launch_shade(false, detailed, s->specular, resume_grid, stream, P); }))) return rc;
+        RT_HIP(hipMemsetAsync(L.d_rounds, 0, sizeof(QueueCounters) * (rounds + 1) * passes, stream));
+        P.portion_next = &L.d_rounds[0].unit_next;       /* the passes of a batch share the cursor over its new paths */
+        for (uint32_t pass = 0; pass < passes; pass++) {
+            QueueCounters *Q = L.d_rounds + (size_t)pass * (rounds + 1);      /* the pass's round records */
+            /* round 0: new paths */
+            P.stats = s->d_stats + KIND_FRESH * RT_STAT_WORDS;
+            P.q = Q; P.q_in = nullptr; P.in_list = nullptr; P.out_list = L.d_parked[0];
+            P.chunk = RT_CHUNK;
+            if ((rc = timed_launch(s, timed, KIND_FRESH, stream, [&]() { launch_shade(true, detailed, s->specular, shade_grid, stream, P); }))) return rc;
+            /* rounds 1 ...: answer the parked queries, resume those paths.  What a round has to do stands in
+             * the previous round's record; launches of rounds that are not needed return at once. */
+            for (uint32_t r = 1; r <= rounds; r++) {
+                TreeParams T;
+                memset(&T, 0, sizeof(T));
+                T.S = P.S; T.list = L.d_parked[(r - 1) & 1]; T.capacity = P.out_capacity; T.finish_below = finish_below;
+                T.q = Q + (r - 1); T.stats = s->d_stats + KIND_TREE * RT_STAT_WORDS;
+                if ((rc = timed_launch(s, timed, KIND_TREE, stream, [&]() {
+                        if (detailed) hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(s->tree_blocks), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, stream, T);
+                        else hipLaunchKernelGGL(rt_tree_kernel<false>, dim3(s->tree_blocks), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, stream, T);
+                    }))) return rc;
+                P.stats = s->d_stats + KIND_RESUME * RT_STAT_WORDS;
+                P.q_in = Q + (r - 1); P.q = Q + r;
+                P.in_list = L.d_parked[(r - 1) & 1]; P.out_list = L.d_parked[r & 1];
+                if ((rc = timed_launch(s, timed, KIND_RESUME, stream, [&]() { launch_shade(false, detailed, s->specular, resume_grid, stream, P); }))) return rc;
+            }
+            /* whatever the rounds left parked: one launch walks those paths to their end */
+            FinishParams F;
+            memset(&F, 0, sizeof(F));
+            F.S = P.S; F.lists[0] = L.d_parked[0]; F.lists[1] = L.d_parked[1]; F.capacity = P.out_capacity;
+            F.rounds = Q; F.last_round = rounds; F.finish_below = finish_below;
+            F.totals = s->d_stats + RT_KINDS * RT_STAT_WORDS;
+            F.samples = P.samples; F.stats = s->d_stats + KIND_FINISH * RT_STAT_WORDS;
+            F.seed0 = P.seed0; F.seed1 = P.seed1; F.max_segments = P.max_segments; F.half_w = P.half_w; F.half_h = P.half_h;
+            if ((rc = timed_launch(s, timed, KIND_FINISH, stream, [&]() { launch_finish(detailed, s->specular, s->finish_blocks, lds, stream, F); }))) return rc;
         }
-        /* whatever the rounds left parked: one launch walks those paths to their end */
-        FinishParams F;
-        memset(&F, 0, sizeof(F));
-        F.S = P.S; F.lists[0] = L.d_parked[0]; F.lists[1] = L.d_parked[1]; F.capacity = P.out_capacity;
-        F.rounds = L.d_rounds; F.last_round = rounds; F.finish_below = finish_below;
-        F.totals = s->d_stats + RT_KINDS * RT_STAT_WORDS;
-        F.samples = P.samples; F.stats = s->d_stats + KIND_FINISH * RT_STAT_WORDS;
-        F.seed0 = P.seed0; F.seed1 = P.seed1; F.max_segments = P.max_segments; F.half_w = P.half_w; F.half_h = P.half_h;
-        if ((rc = timed_launch(s, timed, KIND_FINISH, stream, [&]() { launch_finish(detailed, s->specular, s->finish_blocks, lds, stream, F); }))) return rc;
 
         if (previous_sum) RT_HIP(hipStreamWaitEvent(stream, previous_sum, 0));
         R.samples = L.d_samples;
@@ -1766,16 +1814,19 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
         }
         RT_HIP(hipEventRecord(L.done, stream));
         previous_sum = L.done;
-        s->launches++;
+        s->launches++; s->passes += passes;
         if (K.trace_rounds) {                            /* debugging aid: wait for the batch and print its rounds */
-            std::vector<QueueCounters> q(rounds + 1);
+            std::vector<QueueCounters> q((size_t)(rounds + 1) * passes);
             RT_HIP(hipStreamSynchronize(stream));
-            RT_HIP(hipMemcpy(q.data(), L.d_rounds, sizeof(QueueCounters) * (rounds + 1), hipMemcpyDeviceToHost));
-            for (uint32_t r = 0; r <= rounds; r++) {
-                fprintf(stderr, "batch %llu round %u: parked %u records in %u slots%s\n", (unsigned long long)batch, r, q[r].parked, q[r].out_reserved,
-                        q[r].parked <= finish_below ? " -> finishing launch" : "");
-                if (q[r].parked <= finish_below) break;
-            }
+            RT_HIP(hipMemcpy(q.data(), L.d_rounds, sizeof(QueueCounters) * q.size(), hipMemcpyDeviceToHost));
+            for (uint32_t pass = 0; pass < passes; pass++)
+                for (uint32_t r = 0; r <= rounds; r++) {
+                    const QueueCounters &c = q[(size_t)pass * (rounds + 1) + r];
+                    fprintf(stderr, "batch %llu pass %u round %u: parked %u records in %u slots of %llu%s\n", (unsigned long long)batch, pass, r, c.parked,
+                            c.out_reserved, (unsigned long long)capacity, c.parked <= finish_below ? " -> finishing launch" : "");
+                    if (c.overflow) fprintf(stderr, "batch %llu pass %u round %u: %u records found the list full\n", (unsigned long long)batch, pass, r, c.overflow);
+                    if (c.parked <= finish_below) break;
+                }
         }
     }
     /* the caller's stream goes on when every lane has made its last per-pixel sum */
@@ -1832,7 +1883,7 @@ int rt_gpu_render_region_static(rt_gpu_scene *s, float *device_pixels, uint32_t 
     P.S = s->dev;
     P.S.cam.focal = rt_camera_focal(s->field_of_view, height);
     P.stats = s->d_stats + KIND_FRESH * RT_STAT_WORDS;
-    P.q = q_shade;
+    P.q = q_shade; P.portion_next = &q_shade->unit_next;
     P.samples = samples;
     P.out_list = list; P.out_capacity = RT_STATIC_LIST_SLOTS;
     P.chunk = RT_SMALL_CHUNK;
@@ -2131,7 +2182,7 @@ int rt_gpu_get_stats(rt_gpu_scene *s, rt_gpu_stats *out)
     out->shade_ms = s->kind_ms[KIND_FRESH] + s->kind_ms[KIND_RESUME]; out->tree_ms = s->kind_ms[KIND_TREE];
     out->fresh_ms = s->kind_ms[KIND_FRESH]; out->finish_ms = s->kind_ms[KIND_FINISH];
     out->rounds = w[RT_KINDS * RT_STAT_WORDS]; out->overflowed = w[RT_KINDS * RT_STAT_WORDS + 1];
-    out->launches = s->launches;
+    out->launches = s->launches; out->passes = s->passes;
     if (out->overflowed) return fail(RT_GPU_ERR_DEVICE, "parked-path list overflow (" + std::to_string(out->overflowed) + " paths lost): the frames since the last reset are incomplete");
     return RT_GPU_OK;
 }
@@ -2146,7 +2197,7 @@ int rt_gpu_get_stats_by_kernel(rt_gpu_scene *s, rt_gpu_stats out[4])
     for (int k = 0; k < RT_KINDS; k++) {
         fill_counters(out + k, w + k * RT_STAT_WORDS);
         out[k].kernel_ms = s->kind_ms[k];
-        out[k].launches = s->launches;
+        out[k].launches = s->launches; out[k].passes = s->passes;
     }
     out[KIND_FRESH].shade_ms = out[KIND_FRESH].fresh_ms = s->kind_ms[KIND_FRESH];
     out[KIND_RESUME].shade_ms = s->kind_ms[KIND_RESUME];
@@ -2164,7 +2215,7 @@ int rt_gpu_reset_stats(rt_gpu_scene *s)
     settle_timers(s);
     RT_HIP(hipMemset(s->d_stats, 0, sizeof(uint64_t) * (RT_KINDS * RT_STAT_WORDS + 2)));
     for (int k = 0; k < RT_KINDS; k++) s->kind_ms[k] = 0.0;
-    s->launches = 0; s->samples = 0;
+    s->launches = 0; s->passes = 0; s->samples = 0;
     return RT_GPU_OK;
 }
 

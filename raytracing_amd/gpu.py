@@ -48,10 +48,10 @@ class Stats(C.Structure):
         "tri_tests", "tri_hits", "tex_lookups", "rng_draws", "light_tests", "sphere_tests", "plane_tests",
         "shade_steps", "pop_steps", "tri_steps", "shade_lanes", "pop_lanes", "tri_lanes", "tree_entries")] + [
         ("kernel_ms", C.c_double), ("shade_ms", C.c_double), ("tree_ms", C.c_double), ("fresh_ms", C.c_double), ("finish_ms", C.c_double),
-        ("rounds", C.c_uint64), ("overflowed", C.c_uint64), ("launches", C.c_uint32), ("reserved", C.c_uint32)]
+        ("rounds", C.c_uint64), ("overflowed", C.c_uint64), ("launches", C.c_uint32), ("passes", C.c_uint32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class SceneInfo(C.Structure):

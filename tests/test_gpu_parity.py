@@ -677,6 +677,45 @@ def test_config5_frame_at_4096(gpu_scenes):
     assert gs.stats()["rays"] == rays_whole
 
 
+def test_lists_smaller_than_a_batch_start_its_paths_in_passes(gpu_scenes, monkeypatch):
+    """A parked-list budget far below what every path of the batch would need (dogs and cat: 83 % of
+    the paths park in the first launch): the batch stays whole, its new paths start in several
+    passes (the first launch stops taking new work when its list is nearly full, the rounds carry
+    those paths to their end, the next pass goes on), nothing overflows, and the frame is the
+    frame of the default budgets bit for bit; a window of it equals the oracle's pixels."""
+    import torch
+    sh, gs = gpu_scenes("dogs_and_cat")
+    W = H = 1024
+    spp, seed = 16, 2024
+    a = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    gs.reset_stats()
+    gs.render_region_device(a.data_ptr(), W, H, (0, 0, W, H), spp, seed)
+    torch.cuda.synchronize()
+    st = gs.stats()
+    assert st["passes"] == st["launches"] == 1, st
+    fa = a.cpu().numpy()
+    x0, y0, w, h = 400, 560, 64, 48
+    want_img, want = host.new_image(W, H)
+    oracle_counter(sh, W, H, (x0, y0, w, h), spp, seed, image=(want_img, want))
+    assert L.same_bits(fa[y0:y0 + h, x0:x0 + w], want[y0:y0 + h, x0:x0 + w]).all()
+    # 16.8 M paths; either list would hold 17.8 M records (3.4 GB); give the two lists 3.5 GB together
+    monkeypatch.setenv("RT_GPU_STREAMS", "1")
+    monkeypatch.setenv("RT_GPU_PARKED_MB", "3500")
+    small = gpu.GpuScene(sh)
+    monkeypatch.delenv("RT_GPU_STREAMS")
+    monkeypatch.delenv("RT_GPU_PARKED_MB")
+    for _ in range(2):                               # the second call finds the round records of the first
+        a.zero_()
+        small.render_region_device(a.data_ptr(), W, H, (0, 0, W, H), spp, seed)
+        torch.cuda.synchronize()
+        assert L.same_bits(fa, a.cpu().numpy()).all()
+    st2 = small.stats()
+    assert st2["launches"] == 2 and st2["passes"] > 2 * 2, st2
+    assert st2["overflowed"] == 0 and st2["rays"] == 2 * st["rays"]
+    assert small.info()["work_bytes"] < 4 << 30
+    small.close()
+
+
 def test_full_size_frame_properties(golden, gpu_scenes):
     """dog.obj 1024x1024 64 spp (the benchmark frame): run-to-run identical, identical when cut
     into 8 band sets, and the same picture as the reference's converged image: the means over
