@@ -173,6 +173,9 @@ def main():
                     help="how N devices share a frame: 8-row bands (bit-identical to one device) or sample ranges of "
                          "every pixel, summed in rank order (equal up to float summation order; for small frames)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-process path (process group, packed bands, all-gather, assembly, reductions) even "
+                         "with one rank: a functional check of the RCCL calls on a one-GPU machine")
     ap.add_argument("--frames-per-call", type=int, default=0,
                     help="frames whose shares one render call produces (0 = 1 on one GPU, min(N, 4) when N GPUs share a frame)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
@@ -197,7 +200,11 @@ def main():
         local_rank %= max(1, torch.cuda.device_count())      # ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    shared = world > 1 or args.force_dist              # the frame goes through the band split and the collective
+    if shared:
+        if world == 1:
+            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -209,7 +216,7 @@ def main():
     t0 = time.perf_counter()
     sh = scenes.CONFIGS[args.scene]()                  # parsed model arrays -> triangulated mesh + box tree, texture bytes -> linear floats (host C)
     host_assets_ms = 1e3 * (time.perf_counter() - t0)
-    by_samples = world > 1 and args.split == "samples"
+    by_samples = shared and args.split == "samples"
     my_spp = spp
     # Frame i of a run = samples i*spp ... i*spp + spp - 1 of every pixel (one seed): independent frames
     # that are the same pictures whatever N is.  When several GPUs share a frame, a call renders this
@@ -218,7 +225,7 @@ def main():
     if args.frames_per_call > 0:
         per_call = args.frames_per_call
     else:
-        per_call = 1 if (world == 1 or by_samples) else min(world, 4)
+        per_call = 1 if (not shared or by_samples) else min(world, 4)
     if by_samples:
         per_call = 1
 
@@ -242,7 +249,7 @@ def main():
         sl = Slot()
         sl.index = k
         sl.stream = torch.cuda.Stream()
-        if world > 1:
+        if shared:
             rows = H if by_samples else multi_gpu.packed_rows(world, H, band)
             sl.mine = torch.zeros((per_call, rows, W, 3), dtype=torch.float32, device="cuda")
             sl.gathered = torch.zeros((world, per_call, rows, W, 3), dtype=torch.float32, device="cuda")
@@ -254,7 +261,7 @@ def main():
     if by_samples:
         first_sample, my_spp = multi_gpu.sample_range(rank, world, spp)
         base = dict(max_segments=args.max_segments, flags=gpu.FLAG_ACCUMULATE)
-    elif world > 1:
+    elif shared:
         base = dict(max_segments=args.max_segments, band_rows=band, band_rank=rank, band_count=world,
                     flags=gpu.FLAG_COMPACT_BANDS)
     else:
@@ -275,7 +282,7 @@ def main():
         o.frames = count
         o.lane = sl.index
         g.render_region_device(sl.mine.data_ptr(), W, H, (0, 0, W, H), my_spp, args.seed, o, sl.stream.cuda_stream)
-        if world > 1:
+        if shared:
             with torch.cuda.stream(sl.stream):
                 flat_all, flat_mine = sl.gathered.view(-1, W, 3), sl.mine.view(-1, W, 3)
                 if args.backend == "gloo":               # through host memory
@@ -304,7 +311,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if shared:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -338,7 +345,7 @@ def main():
     timed = g.stats_by_kernel()
     kind_ms = [timed[k]["kernel_ms"] / frames for k in KINDS]
     launches_with_work = g.stats()["rounds"] / frames            # shade launches that had work (first one included)
-    if world > 1:
+    if shared:
         where = "cuda" if args.backend == "nccl" else "cpu"
         t = torch.tensor([elapsed, ms_single] + kind_ms, dtype=torch.float64, device=where)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -362,7 +369,7 @@ def main():
     checksum = float(frame.double().sum().item())
 
     if rank == 0:
-        counters = load_counters(args, W, H, spp) if world == 1 else None
+        counters = load_counters(args, W, H, spp) if not shared else None
         resumed_launches = max(0.0, launches_with_work - 1)
         launches = {"new_paths": 1.0, "resumed_paths": resumed_launches, "tree": resumed_launches, "finish": 1.0}
         kernels = {}
@@ -454,7 +461,7 @@ def main():
                 "rays_per_sample": round(rays / args.steps / (W * H * spp), 3),
                 "ms_per_frame": round(1e3 * elapsed / args.steps, 3),
                 "split": ("sample ranges + all-gather + sum in rank order" if by_samples else
-                          "8-row bands round-robin + all-gather") if world > 1 else "single device",
+                          "8-row bands round-robin + all-gather") if shared else "single device",
                 "scene_handles": 1,
                 "host_threads": 1,
                 "frames_per_call": per_call,
@@ -465,14 +472,14 @@ def main():
             },
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not shared and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sh, W, H)
             except Exception as e:  # the baseline is a side measurement; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if shared:
         dist.barrier()
         dist.destroy_process_group()
     g.close()

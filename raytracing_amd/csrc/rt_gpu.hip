@@ -512,8 +512,19 @@ struct TreeParams {
 #ifndef RT_LEAF_REDO
 #define RT_LEAF_REDO 0                /* the ray that accepted a triangle computes its barycentrics again (0: the pair that won leaves them in LDS) */
 #endif
+#ifndef RT_TREE_STAGE
+#define RT_TREE_STAGE 0               /* 1: node records come through LDS, each fetched by four neighbouring lanes (one 64-byte line per
+                                       * request) instead of four 16-byte requests of the lane that owns the ray (experiment: no gain
+                                       * at equal occupancy, and its 16 KB of LDS per workgroup cost two of five resident workgroups) */
+#endif
+#if RT_TREE_STAGE && (RT_TREE_TOP || RT_TREE_SPECULATE)
+#error "RT_TREE_STAGE replaces the RT_TREE_TOP and RT_TREE_SPECULATE experiments"
+#endif
 #define RT_LEAF_WORDS_PER_WAVE (128u + (RT_LEAF_REDO ? 0u : 128u) + (RT_LEAF_MARKS ? 32u : 0u))   /* LDS words per wave for the leaf passes: 64 keys (2 words), 1024 mark bits, 64 x (beta, gamma) */
-#define RT_TREE_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * RT_LEAF_WORDS_PER_WAVE * 4u + (size_t)RT_TREE_TOP * 64u)   /* bytes per workgroup for the leaf passes and the tree tops */
+#define RT_STAGE_LOAD_WORDS 260u      /* one staged load of a wave: 64 lanes x 16 bytes, and 16 bytes of skew between the four loads
+                                       * (the owners' reads of their records then fall on different LDS banks) */
+#define RT_STAGE_WORDS_PER_WAVE (RT_TREE_STAGE ? 4u * RT_STAGE_LOAD_WORDS : 0u)
+#define RT_TREE_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * (RT_LEAF_WORDS_PER_WAVE + RT_STAGE_WORDS_PER_WAVE) * 4u + (size_t)RT_TREE_TOP * 64u)   /* bytes per workgroup for the leaf passes, the staged node records and the tree tops */
 #if RT_TREE_WAVES
 #define RT_TREE_ATTR __attribute__((amdgpu_waves_per_eu(RT_TREE_WAVES, RT_TREE_WAVES)))
 #else
@@ -542,6 +553,18 @@ rt_tree_kernel(const TreeParams P)
     uint32_t *leaf_marks = leaf_area + 128;              /* 32 words (if RT_LEAF_MARKS) */
     float *leaf_bary = reinterpret_cast<float *>(leaf_area + 128 + (RT_LEAF_MARKS ? 32 : 0));   /* 128 words (unless RT_LEAF_REDO) */
     (void)leaf_bary; (void)leaf_marks;
+#if RT_TREE_STAGE
+    /* Node records through LDS.  A lane that fetched its own 64-byte record with four 16-byte loads made four
+     * requests for one line, and the 64 lanes of a wave 256 per node step: the address and tag pipeline of the
+     * vector memory unit, not arithmetic or latency, was what this kernel waited for (asking for every record
+     * twice made it 53 % slower).  Here the four lanes of a quad fetch the four quarters of ONE record in one
+     * load (a whole line per request: 64 requests per node step), written straight to LDS: load i of a step
+     * serves the rays of lanes 4j + i, and lane L finds its record at word i * 260 + 16 * j of the wave's area. */
+    uint32_t *node_stage = lds + (size_t)RT_BLOCK * P.S.stack_cap + (RT_BLOCK / 64) * RT_LEAF_WORDS_PER_WAVE +
+                           (threadIdx.x >> 6) * RT_STAGE_WORDS_PER_WAVE;
+    const rt::u32x4 *my_record = reinterpret_cast<const rt::u32x4 *>(node_stage + (lane & 3u) * RT_STAGE_LOAD_WORDS + (lane >> 2) * 16u);
+    const uint32_t *nodes_words = reinterpret_cast<const uint32_t *>(P.S.nodes) + (lane & 3u) * 4u;   /* this lane's quarter of a record */
+#endif
 
 #if RT_TREE_TOP
     /* The first records of a mesh's node range are the top levels of its tree (breadth-first order): every walk
@@ -566,9 +589,16 @@ rt_tree_kernel(const TreeParams P)
     uint32_t w15 = 0;
     uint32_t in_cur = 0, in_end = 0;
     bool input_done = false;
+#if RT_TREE_STAGE
+    uint32_t cur = RT_ENTRY_NONE;                        /* entry the lane visits next; its record is (on its way) in the lane's LDS slot */
+#else
     uint32_t cur = RT_ENTRY_NONE;                        /* entry the lane visits next; its record is in ra..rd */
     rt::u32x4 ra = 0, rb = 0, rc = 0, rd = 0;
+#endif
     bool stepped = false;                                /* the lane needs its next record */
+#if defined(RT_ABLATE_TREE_FETCH)
+    uint32_t ablate_word = 0, ab0 = 0, ab1 = 0, ab2 = 0, ab3 = 0;
+#endif
 #if RT_TREE_SPECULATE
     /* the records of the visited node's interior children, requested before its boxes are tested: whichever
      * child the walk turns to next, its record has had the whole box test to arrive */
@@ -576,6 +606,12 @@ rt_tree_kernel(const TreeParams P)
     rt::u32x4 s0a = 0, s0b = 0, s0c = 0, s0d = 0, s1a = 0, s1b = 0, s1c = 0, s1d = 0;
 #endif
 
+#if defined(RT_TREE_CLOCKS)      /* experiment: where a wave's time goes (one wave of the launch prints its clock counts per section) */
+    unsigned long long tick[5] = {0, 0, 0, 0, 0}, tick_prev = __builtin_readcyclecounter(), tick_iterations = 0;
+#define RT_TICK(i) { const unsigned long long now = __builtin_readcyclecounter(); tick[i] += now - tick_prev; tick_prev = now; }
+#else
+#define RT_TICK(i)
+#endif
     auto finish = [&]() {                                /* answer the query: write the hit back */
         uint4 *q = reinterpret_cast<uint4 *>(P.list + (size_t)slot * RT_RECORD_WORDS);
         q[2] = make_uint4(__float_as_uint(h.t), (uint32_t)h.type, h.id, h.inst);
@@ -623,6 +659,7 @@ rt_tree_kernel(const TreeParams P)
         }
         const unsigned long long working = __ballot(busy);
         if (!working) break;
+        RT_TICK(0)
 
         /* ---- node steps by the lane that owns the ray; leaves by the whole wave ------------- */
         const bool want_tri = busy && !stepped && tv.tri_cur < tv.tri_end;
@@ -636,11 +673,16 @@ rt_tree_kernel(const TreeParams P)
         if (run_leaf) {
             /* pairs are numbered ray by ray: ray of lane l owns pairs first..first+count-1 */
             const uint32_t count = want_tri ? tv.tri_end - tv.tri_cur : 0u;
+            /* running sum over the 64 lanes by lane-shifted adds inside the vector unit (rows of 16, then the row
+             * totals carried on): six instructions and no trip through the LDS crossbar, whose latency a scan by
+             * lane exchange pays six times in a row */
             uint32_t incl = count;
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
-                if (lane >= (uint32_t)off) incl += v;
-            }
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);    /* row_shr:1 */
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);    /* row_shr:2 */
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);    /* row_shr:4 */
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);    /* row_shr:8 */
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);    /* row_bcast:15 into rows 1 and 3 */
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);    /* row_bcast:31 into rows 2 and 3 */
             const uint32_t first = incl - count;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             /* owners packed to the low lanes in lane order (= order of their first pairs): packed owner i is
@@ -761,9 +803,16 @@ rt_tree_kernel(const TreeParams P)
                 if (accepted && any_hit) { finish(); stepped = false; }
             }
         }
+        RT_TICK(1)
         if (run_node) {
             if (STATS) { if (lane == 0) cn.pop_steps++; if (want_node) cn.pop_lanes++; }
+#if RT_TREE_STAGE
+            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the records asked for at the end of the previous iteration are in LDS */
+#endif
             if (want_node) {
+#if RT_TREE_STAGE
+                const rt::u32x4 ra = my_record[0], rb = my_record[1], rc = my_record[2], rd = my_record[3];
+#endif
 #if RT_TREE_SPECULATE
                 spec0 = (rd.x & RT_ENTRY_LEAF) ? RT_ENTRY_NONE : rd.x;
                 spec1 = (rd.y & RT_ENTRY_LEAF) ? RT_ENTRY_NONE : rd.y;
@@ -779,7 +828,11 @@ rt_tree_kernel(const TreeParams P)
                 rt::walk_node<STATS>(ra, rb, rc, rd, h, tv, stk, cur, cn); stepped = true;
             }
         }
+        RT_TICK(2)
         /* ---- the one place records are requested: every lane that took a step (or a new ray) ---- */
+#if RT_TREE_STAGE
+        uint32_t want_record = RT_ENTRY_NONE;            /* index of the node record the lane needs next (none) */
+#endif
         if (stepped) {
             stepped = false;
             const rt::u32x4 *q = nullptr;
@@ -788,6 +841,9 @@ rt_tree_kernel(const TreeParams P)
 #endif
             const int next = rt::walk_advance<STATS>(P.S, o, d, h, tv, stk, cur, q, cn);
             if (next == rt::NEXT_NODE) {
+#if RT_TREE_STAGE
+                want_record = tv.node_base + cur;
+#else
 #if RT_TREE_SPECULATE
                 if (child != RT_ENTRY_NONE && child == spec0) { ra = s0a; rb = s0b; rc = s0c; rd = s0d; }
                 else if (child != RT_ENTRY_NONE && child == spec1) { ra = s1a; rb = s1b; rc = s1c; rd = s1d; }
@@ -800,13 +856,45 @@ rt_tree_kernel(const TreeParams P)
                 } else
 #endif
                 { ra = q[0]; rb = q[1]; rc = q[2]; rd = q[3]; }
+#if defined(RT_ABLATE_TREE_FETCH)   /* timing experiment only: every node record is asked for twice (the second time one word per quad) */
+                {
+                    const volatile uint32_t *qv = reinterpret_cast<const volatile uint32_t *>(q);
+                    ablate_word ^= ab0 ^ ab1 ^ ab2 ^ ab3;        /* the previous step's words: long arrived */
+                    ab0 = qv[1]; ab1 = qv[5]; ab2 = qv[9]; ab3 = qv[13];
+                }
+#endif
+#endif
             }
             else if (next == rt::NEXT_DONE) finish();
 #if RT_TREE_SPECULATE
             spec0 = spec1 = RT_ENTRY_NONE;
 #endif
         }
+#if RT_TREE_STAGE
+        /* all lanes: load i fetches the records wanted by lanes 4j + i, a quarter per lane of quad j; an owner's slot
+         * is written only by loads made for it, so a record waits there until its owner's next node step */
+        if (__ballot(want_record != RT_ENTRY_NONE)) {
+#define RT_STAGE_LOAD(i) { \
+                const uint32_t rec = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)want_record, (i) * 0x55, 0xF, 0xF, false); \
+                if (rec != RT_ENTRY_NONE) \
+                    __builtin_amdgcn_global_load_lds(nodes_words + (size_t)rec * 16u, node_stage + (i) * RT_STAGE_LOAD_WORDS, 16, 0, 0); }
+            RT_STAGE_LOAD(0) RT_STAGE_LOAD(1) RT_STAGE_LOAD(2) RT_STAGE_LOAD(3)
+#undef RT_STAGE_LOAD
+        }
+#endif
+        RT_TICK(3)
+#if defined(RT_TREE_CLOCKS)
+        tick_iterations++;
+#endif
     }
+#if defined(RT_ABLATE_TREE_FETCH)
+    if (ablate_word == 0x12345u && P.capacity == 7u) P.list[0] = ablate_word;     /* keeps the extra loads alive */
+#endif
+#if defined(RT_TREE_CLOCKS)
+    if (blockIdx.x == 77 && threadIdx.x == 64)
+        printf("tree wave: %llu iterations; clocks: refill %llu, leaf pass %llu, node step %llu, advance+request %llu\n",
+               tick_iterations, tick[0], tick[1], tick[2], tick[3]);
+#endif
     flush_counters<STATS>(cn, P.stats);
 }
 
@@ -1384,6 +1472,9 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
         s->dev.texture_count = (int32_t)flat.textures.size();
         s->dev.mesh_count = (int32_t)flat.meshes.size();
         s->dev.stack_cap = flat.stack_cap;
+#if defined(RT_STACK_CLAMP)
+        if (s->dev.stack_cap > RT_STACK_CLAMP) s->dev.stack_cap = RT_STACK_CLAMP;
+#endif
         if ((rc = upload(s, flat.lights, &s->dev.lights))) break;
         if ((rc = upload(s, flat.spheres, &s->dev.spheres))) break;
         if ((rc = upload(s, flat.planes, &s->dev.planes))) break;
@@ -1405,7 +1496,7 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
         if ((rc = upload(s, qzero, &qp))) break;
         s->d_queue = reinterpret_cast<QueueCounters *>(const_cast<uint32_t *>(qp));
         {   /* persistent grids: as many workgroups as the device keeps resident */
-            const size_t lds_bytes = (size_t)RT_BLOCK * flat.stack_cap * 4;
+            const size_t lds_bytes = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
             int per_cu_shade = 0, per_cu_tree = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, rt_shade_kernel<true, false, true>, RT_BLOCK, RT_POOL_LDS) != hipSuccess || per_cu_shade < 1) per_cu_shade = 1;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tree, rt_tree_kernel<false>, RT_BLOCK, lds_bytes + RT_TREE_EXTRA_LDS) != hipSuccess || per_cu_tree < 1) per_cu_tree = 1;

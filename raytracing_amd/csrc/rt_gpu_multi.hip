@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -69,6 +70,7 @@ struct Device {
 struct rt_gpu_multi {
     std::vector<Device> dev;
     uint32_t band_rows = 8;
+    bool collective = false;         /* the bands go through RCCL (more than one device, or RT_GPU_MULTI_FORCE_RCCL) */
 };
 
 /* image row y lives in band y / band of rank (band index) % world, at packed row (band index / world) * band + y % band */
@@ -144,7 +146,10 @@ int rt_gpu_multi_create(const rt_scene *scene, int device_count, rt_gpu_multi **
             rc = rt_gpu_set_error(RT_GPU_ERR_DEVICE, "rt_gpu_multi_create: cannot use a device");
         else rc = rt_gpu_scene_create(scene, &d.scene);            /* the scene resident on every device */
     }
-    if (!rc && device_count > 1) {
+    /* RT_GPU_MULTI_FORCE_RCCL: the collective also with one device (a communicator of one rank), so that a
+     * one-GPU machine can check the library loading and the calls */
+    m->collective = device_count > 1 || getenv("RT_GPU_MULTI_FORCE_RCCL") != nullptr;
+    if (!rc && m->collective) {
         if (!g_rccl.load()) rc = rt_gpu_set_error(RT_GPU_ERR_DEVICE, "rt_gpu_multi_create: librccl.so could not be loaded (needed for more than one device)");
         else {
             std::vector<nccl_comm> comms((size_t)device_count);
@@ -209,7 +214,7 @@ int rt_gpu_multi_render_frame(rt_gpu_multi *m, rt_image3f *image, uint32_t spp, 
         rc = rt_gpu_render_region_device(d.scene, d.mine, W, H, whole, spp, seed, &o, d.stream);
     }
     if (!rc) {                                                        /* every device receives every device's bands */
-        if (world > 1) {
+        if (m->collective) {
             int e = g_rccl.group_start();
             for (uint32_t i = 0; i < world && !e; i++) {
                 Device &d = m->dev[i];

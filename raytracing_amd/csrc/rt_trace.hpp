@@ -179,7 +179,11 @@ struct Hit {
 struct Stack {
     uint32_t *base;
     uint32_t stride;
+#if defined(RT_STACK_CLAMP)      /* timing experiment only: a shorter stack, deeper entries overwrite the last one (wrong pictures) */
+    __device__ __forceinline__ uint32_t &at(int i) const { return base[(uint32_t)(i < RT_STACK_CLAMP ? i : RT_STACK_CLAMP - 1) * stride]; }
+#else
     __device__ __forceinline__ uint32_t &at(int i) const { return base[(uint32_t)i * stride]; }
+#endif
 };
 
 /* slab test by division, src/main.c:379-386 / 404-411 */

@@ -483,6 +483,25 @@ def test_c_side_multi_gpu_frame(gpu_scenes):
         gpu.MultiGpuFrame(sh, gpu.lib().rt_gpu_device_count() + 1)
 
 
+def test_c_side_multi_gpu_frame_through_rccl(gpu_scenes, monkeypatch):
+    """The collective of rt_gpu_multi_render_frame with the one device this box has: RT_GPU_MULTI_FORCE_RCCL
+    makes a communicator of one rank (librccl loaded at run time, ncclCommInitAll, ncclAllGather inside a
+    group on the device's stream), so the loading, the symbols and the call sequence are exercised; the
+    frame is rt_gpu_render_region's bit for bit."""
+    sh, gs = gpu_scenes("dog_room")
+    W, H, spp, seed = 64, 45, 2, 31
+    whole_img, whole = host.new_image(W, H)
+    gs.render_region(whole_img, (0, 0, W, H), spp, seed)
+    monkeypatch.setenv("RT_GPU_MULTI_FORCE_RCCL", "1")
+    m = gpu.MultiGpuFrame(sh, 1)
+    monkeypatch.delenv("RT_GPU_MULTI_FORCE_RCCL")
+    for _ in range(2):
+        img, got = host.new_image(W, H)
+        m.render_frame(img, spp, seed)
+        assert L.same_bits(got, whole).all()
+    m.close()
+
+
 def test_sample_split_equals_the_frame_up_to_summation_order(gpu_scenes):
     """The other split over devices: rank r adds samples [first, first + count) of every pixel to zeros,
     the partial sums are added in rank order and scaled once.  Each partial sum is the oracle's own
