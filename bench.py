@@ -368,6 +368,27 @@ def main():
     aflops = algorithmic_flops(det)
     checksum = float(frame.double().sum().item())
 
+    # side measurement, never the headline: the same frame with the opt-in surface-area tree (other boxes, same triangles)
+    sah = None
+    if not shared and args.scene in ("dog_room", "three_dogs", "dogs_and_cat"):
+        t1 = time.perf_counter()
+        sh2 = scenes.CONFIGS[args.scene](tree="sah", leaf_triangles=8)
+        sah_assets_ms = 1e3 * (time.perf_counter() - t1)
+        g2 = gpu.GpuScene(sh2)
+        buf2 = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        times = []
+        for k in range(4):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            g2.render_region_device(buf2.data_ptr(), W, H, (0, 0, W, H), spp, args.seed, gpu.Options(max_segments=args.max_segments))
+            torch.cuda.synchronize()
+            times.append(1e3 * (time.perf_counter() - t1))
+        sah = {"ms_per_frame_single": round(sorted(times[1:])[1], 3), "host_assets_ms": round(sah_assets_ms, 1),
+               "frame_checksum_seed0": float(buf2.double().sum().item()),
+               "note": "rt_host_mesh_build_tree_sah, 8 triangles per leaf: not the reference's tree (pictures agree except where "
+                       "the tree shape is observable); compare with ms_per_frame_single"}
+        g2.close()
+
     if rank == 0:
         counters = load_counters(args, W, H, spp) if not shared else None
         resumed_launches = max(0.0, launches_with_work - 1)
@@ -472,6 +493,8 @@ def main():
             },
             "roofline": roofline,
         }
+        if sah:
+            out["surface_area_tree"] = sah
         if not shared and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sh, W, H)

@@ -18,6 +18,14 @@ extern "C" {
  * reference.  Returns 0, or <0 on bad input / out of memory. */
 int rt_host_mesh_build_tree(rt_mesh *mesh);
 
+/* A second builder with no counterpart in the reference: per node the axis and plane of least
+ * surface-area cost over 16 centroid bins; a node of more than leaf_triangles (0 = 4) is split as long as
+ * a plane lowers the cost, and always when it holds more than 16.  Same
+ * records as above (so the oracle, the flattener and the kernels take it unchanged), far fewer box and
+ * triangle tests per ray; pictures agree with the reference tree's except where the tree shape shows
+ * (flat boxes, equal distances).  Replaces the mesh's current tree. */
+int rt_host_mesh_build_tree_sah(rt_mesh *mesh, uint32_t leaf_triangles);
+
 /* Replaces the body of load_mesh after the OBJ parse (reference:
  * src/main.c:183-258): copies the parser's arrays (entry 0 of each is the
  * parser's dummy), applies the axis permutation, splits every polygon into a

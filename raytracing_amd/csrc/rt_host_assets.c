@@ -127,6 +127,183 @@ int rt_host_mesh_build_tree(rt_mesh *mesh)
     return 0;
 }
 
+/* ---- a second builder: surface-area heuristic over binned centroids ---------------------------
+ *
+ * Not the reference's tree (src/main.c:92-175 splits the longest axis at its midpoint and stops at 16
+ * triangles): this one picks, per node, the axis and plane that minimise
+ *     area(left box) * count(left) + area(right box) * count(right)
+ * over 16 bins per axis, and stops at small leaves.  Same records (rt_mesh_node: box, adjacent child pair,
+ * first/last triangle of the in-place permuted face table), so everything downstream is unchanged; rays
+ * visit fewer boxes and far fewer triangles.  The picture differs from the reference tree's only where the
+ * tree shape is observable (flat boxes that are never entered, which of two equal distances wins): an
+ * opt-in for hosts that want speed over bit-for-bit agreement with the reference's builder. */
+#define SAH_BINS 16
+#define SAH_BALANCED_BELOW 40u      /* from this depth on nodes are cut at the median (bounds the depth) */
+
+typedef struct sah_tri { float lo[3], hi[3], c[3]; } sah_tri;
+typedef struct sah_ctx { rt_mesh *mesh; sah_tri *tri; node_pool *pool; uint32_t leaf_max; } sah_ctx;
+
+static inline float half_area(const float lo[3], const float hi[3])
+{
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+static void sah_swap(sah_ctx *cx, uint32_t a, uint32_t b)
+{
+    if (a == b) return;
+    rt_triangle f = cx->mesh->faces[a]; cx->mesh->faces[a] = cx->mesh->faces[b]; cx->mesh->faces[b] = f;
+    sah_tri t = cx->tri[a]; cx->tri[a] = cx->tri[b]; cx->tri[b] = t;
+}
+
+static void sah_node(sah_ctx *cx, rt_mesh_node *node, uint32_t depth);
+typedef struct sah_job { sah_ctx *cx; rt_mesh_node *node; uint32_t depth; } sah_job;
+static void *sah_thread(void *arg)
+{
+    sah_job *job = arg;
+    sah_node(job->cx, job->node, job->depth);
+    return NULL;
+}
+
+static void sah_node(sah_ctx *cx, rt_mesh_node *node, uint32_t depth)
+{
+    rt_mesh *mesh = cx->mesh;
+    uint32_t seen = __atomic_load_n(&mesh->tree_depth, __ATOMIC_RELAXED);
+    while (depth > seen && !__atomic_compare_exchange_n(&mesh->tree_depth, &seen, depth, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    const uint32_t first = node->first_triangle_id, last = node->last_triangle_id, count = last - first + 1;
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    float clo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, chi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (uint32_t i = first; i <= last; i++) {
+        const sah_tri *t = cx->tri + i;
+        for (int k = 0; k < 3; k++) {
+            lo[k] = fsel_min(lo[k], t->lo[k]); hi[k] = fsel_max(hi[k], t->hi[k]);
+            clo[k] = fsel_min(clo[k], t->c[k]); chi[k] = fsel_max(chi[k], t->c[k]);
+        }
+    }
+    node->bbox.min.x = lo[0]; node->bbox.min.y = lo[1]; node->bbox.min.z = lo[2];
+    node->bbox.max.x = hi[0]; node->bbox.max.y = hi[1]; node->bbox.max.z = hi[2];
+    node->childs = NULL;
+    if (count <= cx->leaf_max || depth >= TREE_DEPTH_LIMIT) return;
+
+    uint32_t pivot = first;                          /* first triangle of the right child */
+    int found = 0;
+    if (depth < SAH_BALANCED_BELOW) {
+        float best = FLT_MAX; int best_axis = -1, best_bin = 0;
+        for (int axis = 0; axis < 3; axis++) {
+            const float extent = chi[axis] - clo[axis];
+            if (!(extent > 0)) continue;
+            const float scale = (float)SAH_BINS / extent;
+            uint32_t n[SAH_BINS]; float blo[SAH_BINS][3], bhi[SAH_BINS][3];
+            for (int b = 0; b < SAH_BINS; b++) {
+                n[b] = 0;
+                for (int k = 0; k < 3; k++) { blo[b][k] = FLT_MAX; bhi[b][k] = -FLT_MAX; }
+            }
+            for (uint32_t i = first; i <= last; i++) {
+                const sah_tri *t = cx->tri + i;
+                int b = (int)((t->c[axis] - clo[axis]) * scale);
+                if (b < 0) b = 0;
+                if (b >= SAH_BINS) b = SAH_BINS - 1;
+                n[b]++;
+                for (int k = 0; k < 3; k++) { blo[b][k] = fsel_min(blo[b][k], t->lo[k]); bhi[b][k] = fsel_max(bhi[b][k], t->hi[k]); }
+            }
+            float right_area[SAH_BINS]; uint32_t right_n[SAH_BINS];
+            float rlo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, rhi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+            uint32_t rn = 0;
+            for (int b = SAH_BINS - 1; b > 0; b--) {
+                rn += n[b];
+                for (int k = 0; k < 3; k++) { rlo[k] = fsel_min(rlo[k], blo[b][k]); rhi[k] = fsel_max(rhi[k], bhi[b][k]); }
+                right_n[b] = rn; right_area[b] = rn ? half_area(rlo, rhi) : 0.0f;
+            }
+            float llo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, lhi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+            uint32_t ln = 0;
+            for (int b = 0; b + 1 < SAH_BINS; b++) {         /* plane after bin b */
+                ln += n[b];
+                for (int k = 0; k < 3; k++) { llo[k] = fsel_min(llo[k], blo[b][k]); lhi[k] = fsel_max(lhi[k], bhi[b][k]); }
+                if (!ln || !right_n[b + 1]) continue;
+                const float cost = half_area(llo, lhi) * (float)ln + right_area[b + 1] * (float)right_n[b + 1];
+                if (cost < best) { best = cost; best_axis = axis; best_bin = b; }
+            }
+        }
+        /* a leaf of up to 16 triangles stays a leaf when no plane beats testing them all here */
+        if (best_axis >= 0 && !(count <= LEAF_MAX_TRIANGLES && best >= half_area(lo, hi) * (float)count)) {
+            const float scale = (float)SAH_BINS / (chi[best_axis] - clo[best_axis]);
+            for (uint32_t i = first; i <= last; i++) {
+                int b = (int)((cx->tri[i].c[best_axis] - clo[best_axis]) * scale);
+                if (b < 0) b = 0;
+                if (b >= SAH_BINS) b = SAH_BINS - 1;
+                if (b <= best_bin) sah_swap(cx, pivot++, i);
+            }
+            found = pivot > first && pivot <= last;
+        } else if (best_axis >= 0 || count <= LEAF_MAX_TRIANGLES) {
+            if (count <= LEAF_MAX_TRIANGLES) return;
+        }
+    }
+    if (!found) {
+        /* coincident centroids, or deep in a lopsided branch: cut at the median of the widest centroid axis
+         * (selection by repeated partition; equal keys are split by position) */
+        int axis = 0;
+        if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+        if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+        const uint32_t mid = first + count / 2;
+        uint32_t a = first, b = last;
+        while (a < b) {
+            const float key = cx->tri[a + (b - a) / 2].c[axis];
+            uint32_t i = a, j = b;
+            while (i <= j) {
+                while (cx->tri[i].c[axis] < key) i++;
+                while (cx->tri[j].c[axis] > key) j--;
+                if (i <= j) { sah_swap(cx, i, j); i++; if (j == 0) break; j--; }
+            }
+            if (mid <= j) b = j; else if (mid >= i) a = i; else break;
+        }
+        pivot = mid;
+    }
+
+    rt_mesh_node *pair = cx->pool->nodes + __atomic_fetch_add(&cx->pool->used, 2, __ATOMIC_RELAXED);
+    memset(pair, 0, 2 * sizeof(*pair));
+    node->childs = pair;
+    pair[0].first_triangle_id = first;  pair[0].last_triangle_id = pivot - 1;
+    pair[1].first_triangle_id = pivot;  pair[1].last_triangle_id = last;
+    pthread_t helper;
+    sah_job job = { cx, pair + 0, depth + 1 };
+    int forked = depth <= FORK_LEVELS && count >= FORK_MIN_TRIANGLES && pthread_create(&helper, NULL, sah_thread, &job) == 0;
+    if (!forked) sah_node(cx, pair + 0, depth + 1);
+    sah_node(cx, pair + 1, depth + 1);
+    if (forked) pthread_join(helper, NULL);
+}
+
+int rt_host_mesh_build_tree_sah(rt_mesh *mesh, uint32_t leaf_triangles)
+{
+    if (!mesh || !mesh->faces || mesh->face_count == 0) return -1;
+    if (leaf_triangles == 0) leaf_triangles = 4;
+    if (leaf_triangles > LEAF_MAX_TRIANGLES) leaf_triangles = LEAF_MAX_TRIANGLES;
+    node_pool pool;
+    pool.cap = 2 * (size_t)mesh->face_count + 2;
+    pool.used = 0;
+    pool.nodes = calloc(pool.cap, sizeof(rt_mesh_node));
+    sah_tri *tri = malloc(sizeof(sah_tri) * (size_t)mesh->face_count);
+    if (!pool.nodes || !tri) { free(pool.nodes); free(tri); return -2; }
+    for (uint32_t i = 0; i < mesh->face_count; i++) {
+        sah_tri *t = tri + i;
+        for (int k = 0; k < 3; k++) { t->lo[k] = FLT_MAX; t->hi[k] = -FLT_MAX; }
+        for (int c = 0; c < 3; c++) {
+            const rt_vec3f *p = mesh->points + mesh->faces[i].ids[c].vertexId;
+            for (int k = 0; k < 3; k++) { t->lo[k] = fsel_min(t->lo[k], axis_of(p, k)); t->hi[k] = fsel_max(t->hi[k], axis_of(p, k)); }
+        }
+        for (int k = 0; k < 3; k++) t->c[k] = 0.5f * t->lo[k] + 0.5f * t->hi[k];
+    }
+    free(mesh->root.childs);                         /* a tree built before (the pool starts at the root's first child) */
+    mesh->tree_depth = 0;
+    memset(&mesh->root, 0, sizeof(mesh->root));
+    mesh->root.first_triangle_id = 0;
+    mesh->root.last_triangle_id = mesh->face_count - 1;
+    sah_ctx cx = { mesh, tri, &pool, leaf_triangles };
+    sah_node(&cx, &mesh->root, 1);
+    free(tri);
+    if (!mesh->root.childs) free(pool.nodes);
+    return 0;
+}
+
 /* OBJ arrays -> rt_mesh; src/main.c:183-258.  Index 0 of each attribute array
  * is the parser's dummy entry and indices are used 1-based as they come.
  * Coordinates are permuted (x,y,z) -> (y,z,x) by the two swaps y<->z, x<->z. */

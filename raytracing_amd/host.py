@@ -23,6 +23,8 @@ def lib():
         L = C.CDLL(path)
         L.rt_host_mesh_build_tree.argtypes = [C.POINTER(T.Mesh)]
         L.rt_host_mesh_build_tree.restype = C.c_int
+        L.rt_host_mesh_build_tree_sah.argtypes = [C.POINTER(T.Mesh), C.c_uint32]
+        L.rt_host_mesh_build_tree_sah.restype = C.c_int
         L.rt_host_mesh_from_obj_arrays.argtypes = [
             C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
             C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(T.Mesh)]
@@ -43,8 +45,12 @@ def lib():
     return _LIB
 
 
-def mesh_from_obj_arrays(positions, texcoords, normals, indices_ptn, face_vertices):
-    """OBJ parser arrays (entry 0 of each attribute array = the parser's dummy) -> T.Mesh."""
+def mesh_from_obj_arrays(positions, texcoords, normals, indices_ptn, face_vertices, tree="reference", leaf_triangles=0):
+    """OBJ parser arrays (entry 0 of each attribute array = the parser's dummy) -> T.Mesh.
+    tree: "reference" = the reference's splitting rule (its tree and face order, node for node);
+    "sah" = the surface-area builder (rt_host_mesh_build_tree_sah; leaves of at most leaf_triangles, 0 = 4)."""
+    if tree not in ("reference", "sah"):
+        raise ValueError(f"unknown tree builder {tree!r}")
     positions = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
     texcoords = np.ascontiguousarray(texcoords, dtype=np.float32).reshape(-1, 2)
     normals = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
@@ -59,6 +65,10 @@ def mesh_from_obj_arrays(positions, texcoords, normals, indices_ptn, face_vertic
         len(face_vertices), C.byref(mesh))
     if rc != 0:
         raise RuntimeError(f"rt_host_mesh_from_obj_arrays failed: {rc}")
+    if tree == "sah":
+        rc = lib().rt_host_mesh_build_tree_sah(C.byref(mesh), leaf_triangles)
+        if rc != 0:
+            raise RuntimeError(f"rt_host_mesh_build_tree_sah failed: {rc}")
     return mesh
 
 

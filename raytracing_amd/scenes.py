@@ -121,12 +121,14 @@ def instance(mesh, position, material_id, mirrored_x=False):
 _ASSET_CACHE = {}
 
 
-def _load_mesh(name):
-    if name not in _ASSET_CACHE:
+def _load_mesh(name, tree="reference", leaf_triangles=0):
+    key = name if tree == "reference" else f"{name}/{tree}/{leaf_triangles}"
+    if key not in _ASSET_CACHE:
         with np.load(os.path.join(ASSET_DIR, name + "_obj.npz"), allow_pickle=False) as z:
-            _ASSET_CACHE[name] = host.mesh_from_obj_arrays(
-                z["positions"], z["texcoords"], z["normals"], z["indices"], z["face_vertices"])
-    return _ASSET_CACHE[name]
+            _ASSET_CACHE[key] = host.mesh_from_obj_arrays(
+                z["positions"], z["texcoords"], z["normals"], z["indices"], z["face_vertices"],
+                tree=tree, leaf_triangles=leaf_triangles)
+    return _ASSET_CACHE[key]
 
 
 def _load_texture(name):
@@ -137,10 +139,11 @@ def _load_texture(name):
     return _ASSET_CACHE[key]
 
 
-def load_dog_mesh():
+def load_dog_mesh(tree="reference", leaf_triangles=0):
     """The dog model (71 968 triangles) from its parsed-OBJ arrays, triangulated and
-    given its box tree by the host C code (include/rt_host.h)."""
-    return _load_mesh("dog")
+    given its box tree by the host C code (include/rt_host.h): the reference's tree, or
+    (tree="sah") the surface-area builder's."""
+    return _load_mesh("dog", tree, leaf_triangles)
 
 
 def load_dog_texture():
@@ -148,9 +151,9 @@ def load_dog_texture():
     return _load_texture("dog")
 
 
-def load_cat_mesh():
+def load_cat_mesh(tree="reference", leaf_triangles=0):
     """The cat model (70 576 triangles), the second mesh of the 4096 x 4096 configuration."""
-    return _load_mesh("cat")
+    return _load_mesh("cat", tree, leaf_triangles)
 
 
 def load_cat_texture():
@@ -186,17 +189,17 @@ def diffuse_room():
                        room_planes(), room_lights(), [])
 
 
-def dog_room(mesh=None, texture=None, position=(0.0, -10.0, 0.0)):
+def dog_room(mesh=None, texture=None, position=(0.0, -10.0, 0.0), tree="reference", leaf_triangles=0):
     """Config 4 (the headline benchmark): the room with one textured dog."""
-    mesh = mesh if mesh is not None else load_dog_mesh()
+    mesh = mesh if mesh is not None else load_dog_mesh(tree, leaf_triangles)
     texture = texture if texture is not None else load_dog_texture()
     return SceneHandle("dog_room", room_camera(), room_materials(texture), [], room_planes(),
                        room_lights(), [instance(mesh, position, 8)], keep=[mesh, texture])
 
 
-def three_dogs(mesh=None, texture=None):
+def three_dogs(mesh=None, texture=None, tree="reference", leaf_triangles=0):
     """Config 5 / the reference's own main() scene: mirror dog (mirrored in x), textured dog, glass dog."""
-    mesh = mesh if mesh is not None else load_dog_mesh()
+    mesh = mesh if mesh is not None else load_dog_mesh(tree, leaf_triangles)
     texture = texture if texture is not None else load_dog_texture()
     meshes = [instance(mesh, (-25.0, -10.0, 0.0), 5, mirrored_x=True),
               instance(mesh, (25.0, -10.0, 0.0), 8),
@@ -205,13 +208,13 @@ def three_dogs(mesh=None, texture=None):
                        room_lights(), meshes, keep=[mesh, texture])
 
 
-def dogs_and_cat():
+def dogs_and_cat(tree="reference", leaf_triangles=0):
     """Config 5 as the benchmark list words it (dog + cat meshes + mirrors): two distinct meshes, two
     textures, four instances (mirror dog mirrored in x, textured dog, textured cat, glass cat) and
     the mirror sphere of the room.  The reference's source has no such scene (its main() instances the
     dog three times and never loads the cat), so the placement is this build's; both models go
     through the same loader (src/main.c:177-262)."""
-    dog, cat = load_dog_mesh(), load_cat_mesh()
+    dog, cat = load_dog_mesh(tree, leaf_triangles), load_cat_mesh(tree, leaf_triangles)
     dog_tex, cat_tex = load_dog_texture(), load_cat_texture()
     mats = room_materials(dog_tex) + [_material(diffuse=WHITE, texture=cat_tex)]     # 9: the cat's diffuse map
     meshes = [instance(dog, (-30.0, -10.0, 0.0), 5, mirrored_x=True),

@@ -735,6 +735,55 @@ def test_lists_smaller_than_a_batch_start_its_paths_in_passes(gpu_scenes, monkey
     small.close()
 
 
+def test_surface_area_tree_scene(gpu_scenes):
+    """The opt-in second tree builder (rt_host_mesh_build_tree_sah: other boxes, other face order, small
+    leaves, two distinct meshes): the device renders the oracle's bits for the scene it is given, probes
+    agree with the one-by-one walk word for word, the tree kernel makes fewer box and triangle tests
+    than with the reference's tree, and the picture is the reference tree's picture except where the
+    tree shape is observable (bounds stated below)."""
+    sh_ref, gs_ref = gpu_scenes("dogs_and_cat")
+    sh = scenes.dogs_and_cat(tree="sah", leaf_triangles=4)
+    gs = gpu.GpuScene(sh)
+    W, H, spp, seed = 112, 80, 6, 404
+    img, got = host.new_image(W, H)
+    gs.reset_stats()
+    gs.render_region(img, (0, 0, W, H), spp, seed, gpu.Options(flags=gpu.FLAG_DETAILED_STATS))
+    st = gs.stats()
+    assert L.same_bits(got, oracle_counter(sh, W, H, (0, 0, W, H), spp, seed)).all()
+    img_ref, ref = host.new_image(W, H)
+    gs_ref.reset_stats()
+    gs_ref.render_region(img_ref, (0, 0, W, H), spp, seed, gpu.Options(flags=gpu.FLAG_DETAILED_STATS))
+    st_ref = gs_ref.stats()
+    assert st["tri_tests"] < 0.5 * st_ref["tri_tests"] and st["interior_pops"] < 1.6 * st_ref["interior_pops"]
+    # same samples, same arithmetic per primitive: a pixel differs only if one of its paths met a flat box or two
+    # equal distances; such a path then continues differently
+    same = L.same_bits(got, ref).all(axis=2)
+    assert same.mean() > 0.97, same.mean()
+    assert abs(float(got.mean()) - float(ref.mean())) < 0.01 * float(ref.mean())
+    rng = np.random.default_rng(11)
+    n = 4000
+    o = rng.uniform(-40.0, 40.0, (n, 3)).astype(np.float32)
+    o[:, 1] = np.abs(o[:, 1]) * 0.5
+    target = np.array([[-30, -5, 0], [25, -5, 10], [-5, -5, -30], [0, -5, 35]], np.float32)[rng.integers(0, 4, n)]
+    target = target + rng.uniform(-6.0, 6.0, (n, 3)).astype(np.float32)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    rays = np.hstack([o, d]).astype(np.float32)
+    a = _result_fields(gs.find_ray_hit(rays, FLT_MAX))
+    b = _result_fields(gs.find_ray_hit(rays, FLT_MAX, serial=True))
+    hits = 0
+    for f in a:
+        assert L.same_bits(a[f], b[f]).all(), f
+    want = (T.RayResult * 400)()
+    for i in range(400):
+        ray = T.Ray(T.Vec3f(*rays[i, :3].tolist()), T.Vec3f(*rays[i, 3:].tolist()))
+        L.oracle().orc_find_ray_hit(sh.ptr, C.byref(ray), FLT_MAX, C.byref(want[i]), None)
+    w = _result_fields(want)
+    for f in a:
+        assert L.same_bits(a[f][:400], w[f]).all(), f
+    gs.close()
+
+
 def test_full_size_frame_properties(golden, gpu_scenes):
     """dog.obj 1024x1024 64 spp (the benchmark frame): run-to-run identical, identical when cut
     into 8 band sets, and the same picture as the reference's converged image: the means over

@@ -148,3 +148,74 @@ def test_progressive_checkpoint_header_checks():
                                (sums, [6, 4, 2]), (np.full((4, 6, 3), np.nan, np.float32), [6, 4, 2, 1, 0, 0])]:
         with pytest.raises(ValueError):
             progressive.check_checkpoint(bad_sums, bad_meta)
+
+
+def _check_tree(mesh, leaf_max):
+    """A valid tree over the mesh's face table: leaves in order cover every triangle once, every box
+    is the exact bounds of its triangles' corners, children split their parent's range."""
+    tree = host.mesh_dump_tree(mesh)
+    faces = host.mesh_faces_array(mesh)
+    pts = np.ctypeslib.as_array(C.cast(mesh.points, C.POINTER(C.c_float)), shape=(mesh.point_count, 3))
+    corners = pts[faces[:, ::3]]                               # (triangles, 3 corners, xyz)
+    tri_lo, tri_hi = corners.min(axis=1), corners.max(axis=1)
+    first, last = tree[:, 6].astype(np.int64), (tree[:, 7] & 0x7FFFFFFF).astype(np.int64)
+    interior = (tree[:, 7] >> 31).astype(bool)
+    leaves = ~interior
+    assert (np.sort(first[leaves]) == first[leaves]).all()      # depth-first, child 0 first: leaves come in range order
+    assert first[leaves][0] == 0 and last[leaves][-1] == mesh.face_count - 1
+    assert (first[leaves][1:] == last[leaves][:-1] + 1).all()
+    assert (last[leaves] - first[leaves] + 1).max() <= leaf_max
+    lo_sum = np.minimum.reduceat(tri_lo, first[leaves], axis=0)
+    hi_sum = np.maximum.reduceat(tri_hi, first[leaves], axis=0)
+    boxes = tree[:, :6].view(np.float32)
+    assert L.same_bits(boxes[leaves, :3], lo_sum).all() and L.same_bits(boxes[leaves, 3:], hi_sum).all()
+    # interior boxes: bounds of their range, through a prefix structure over the leaves
+    order = np.flatnonzero(interior)
+    for i in order[:: max(1, len(order) // 200)]:              # a sample of interior nodes (the root included)
+        assert L.same_bits(boxes[i, :3], tri_lo[first[i]:last[i] + 1].min(axis=0)).all()
+        assert L.same_bits(boxes[i, 3:], tri_hi[first[i]:last[i] + 1].max(axis=0)).all()
+        assert first[i + 1] == first[i]                        # child 0 follows its parent
+
+
+@pytest.mark.parametrize("leaf", [16, 8, 4, 1])
+def test_surface_area_tree_is_a_valid_tree_over_the_same_triangles(leaf):
+    """rt_host_mesh_build_tree_sah (no counterpart in the reference): the face table is a permutation
+    of the reference builder's, the tree is valid, shallower than the reference's 24 levels for the
+    dog at 16 triangles per leaf, and two builds (threaded) give the same tree."""
+    ref = scenes.load_dog_mesh()
+    with np.load(scenes.os.path.join(scenes.ASSET_DIR, "dog_obj.npz"), allow_pickle=False) as z:
+        args = [z[k] for k in ("positions", "texcoords", "normals", "indices", "face_vertices")]
+    mesh = host.mesh_from_obj_arrays(*args, tree="sah", leaf_triangles=leaf)
+    again = host.mesh_from_obj_arrays(*args, tree="sah", leaf_triangles=leaf)
+    assert mesh.face_count == ref.face_count
+    a, b = host.mesh_faces_array(ref), host.mesh_faces_array(mesh)
+    assert (a[np.lexsort(a.T[::-1])] == b[np.lexsort(b.T[::-1])]).all()
+    _check_tree(mesh, 16)                                      # a node above `leaf` triangles that no plane improves stays a leaf (at most 16)
+    cen = host.mesh_census(mesh)
+    assert cen["depth"] == mesh.tree_depth <= 40
+    assert cen["leaves"] >= mesh.face_count / (2.5 * leaf)
+    if leaf == 16:
+        assert cen["depth"] < 24
+    assert sha(host.mesh_dump_tree(mesh)) == sha(host.mesh_dump_tree(again))
+    assert sha(host.mesh_faces_array(mesh)) == sha(host.mesh_faces_array(again))
+    for m in (mesh, again):
+        host.lib().rt_host_mesh_free(C.byref(m))
+
+
+def test_surface_area_tree_on_degenerate_input():
+    """Coincident centroids cannot be separated by a plane: the builder cuts at the median by position
+    until at most 16 triangles are left (splitting those further could not spare a ray any test)."""
+    pos = np.array([[0, 0, 0], [0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    tc = np.zeros((2, 2), np.float32)
+    nr = np.array([[0, 0, 0], [0, 0, 1]], np.float32)
+    n = 100
+    idx = np.tile(np.array([[1, 1, 1], [2, 1, 1], [3, 1, 1]], np.uint32), (n, 1))
+    mesh = host.mesh_from_obj_arrays(pos, tc, nr, idx, np.full(n, 3, np.uint32), tree="sah", leaf_triangles=4)
+    cen = host.mesh_census(mesh)
+    assert mesh.face_count == n and cen["max_leaf"] <= 16 and 4 <= cen["depth"] <= 8
+    _check_tree(mesh, 16)
+    host.lib().rt_host_mesh_free(C.byref(mesh))
+
+
+def test_reference_tree_can_be_checked_the_same_way():
+    _check_tree(scenes.load_dog_mesh(), 16)

@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
 """Benchmark frames one at a time with every launch timed: device time per kind of launch, rounds;
 then one frame with the detailed counters: work counts and scheduler step occupancy.
-environment: SCENE, SIZE, SPP, FRAMES, WORLD (render rank 1's packed share of WORLD ranks); RT_GPU_LIB selects a library variant."""
+environment: SCENE, SIZE, SPP, FRAMES, TREE (sah) and LEAF (triangles per leaf), WORLD (render rank 1's packed share of WORLD ranks); RT_GPU_LIB selects a library variant."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raytracing_amd import gpu, scenes
 W = H = int(os.environ.get("SIZE", "1024")); spp = int(os.environ.get("SPP", "64")); n = int(os.environ.get("FRAMES", "4"))
-sh = scenes.CONFIGS[os.environ.get("SCENE", "dog_room")]()
+tree_kw = dict(tree=os.environ["TREE"], leaf_triangles=int(os.environ.get("LEAF", "0"))) if os.environ.get("TREE") else {}
+t_assets = time.perf_counter()
+sh = scenes.CONFIGS[os.environ.get("SCENE", "dog_room")](**tree_kw)
+t_assets = 1e3 * (time.perf_counter() - t_assets)
 g = gpu.GpuScene(sh)
+if tree_kw:
+    from raytracing_amd import host
+    print(f"tree {tree_kw}: host assets {t_assets:.0f} ms, " + ", ".join(f"mesh {i}: {host.mesh_census(sh.meshes[i].mesh.contents)}" for i in range(sh.scene.mesh_count)), g.info())
 world = int(os.environ.get("WORLD", "1"))
 def opts(**kw):
     if world > 1:
