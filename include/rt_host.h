@@ -40,6 +40,14 @@ int rt_host_mesh_from_obj_arrays(const float *positions, uint32_t position_count
 
 void rt_host_mesh_free(rt_mesh *mesh);
 
+/* A prepared mesh (what load_mesh, src/main.c:177-262, leaves in memory: attribute arrays, permuted
+ * face table, tree) as one file, so that a later run skips the OBJ parse and the tree build.  `key`
+ * is the caller's content key (a hash of the source model and the builder's parameters); load refuses
+ * a file written under another key (-7), a missing file (-3) and a malformed one (-4, -5: every
+ * index, range and count is checked).  No counterpart in the reference. */
+int rt_host_mesh_save(const rt_mesh *mesh, uint64_t key, const char *path);
+int rt_host_mesh_load(const char *path, uint64_t key, rt_mesh *out);
+
 /* {nodes, leaves, deepest level (root = 1), largest leaf} */
 void rt_host_mesh_census(const rt_mesh *mesh, uint32_t out[4]);
 

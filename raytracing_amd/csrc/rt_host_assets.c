@@ -419,6 +419,129 @@ size_t rt_host_mesh_dump_tree(const rt_mesh *mesh, uint32_t *words8_per_node)
     return at;
 }
 
+/* ---- a prepared mesh as one file ---------------------------------------------------------------
+ * What load_mesh (src/main.c:177-262) leaves in memory -- attribute arrays, the permuted face table,
+ * the tree -- written out so that a later run maps it back without parsing or building anything.
+ * Layout: a 64-byte header {magic, version, point, texcoord, normal, face, node counts, tree depth,
+ * 64-bit key}, then points, texcoords, normals, faces, and the tree as rt_host_mesh_dump_tree writes
+ * it (8 words per node, depth first).  The key is the caller's (a hash of the source model and of the
+ * builder's parameters): a file with another key is refused. */
+#include <stdio.h>
+#define MESH_FILE_MAGIC 0x4D545231u   /* "1RTM" */
+#define MESH_FILE_VERSION 1u
+typedef struct mesh_file_header {
+    uint32_t magic, version, points, texcoords, normals, faces, nodes, tree_depth;
+    uint64_t key;
+    uint32_t reserved[6];
+} mesh_file_header;
+
+int rt_host_mesh_save(const rt_mesh *mesh, uint64_t key, const char *path)
+{
+    if (!mesh || !path || !mesh->faces) return -1;
+    uint32_t cen[4];
+    rt_host_mesh_census(mesh, cen);
+    uint32_t *tree = malloc((size_t)cen[0] * 32);
+    if (!tree) return -2;
+    rt_host_mesh_dump_tree(mesh, tree);
+    mesh_file_header h;
+    memset(&h, 0, sizeof(h));
+    h.magic = MESH_FILE_MAGIC; h.version = MESH_FILE_VERSION;
+    h.points = mesh->point_count; h.texcoords = mesh->texcoord_count; h.normals = mesh->normal_count;
+    h.faces = mesh->face_count; h.nodes = cen[0]; h.tree_depth = mesh->tree_depth; h.key = key;
+    FILE *f = fopen(path, "wb");
+    int ok = f != NULL;
+    ok = ok && fwrite(&h, sizeof(h), 1, f) == 1;
+    ok = ok && (!h.points || fwrite(mesh->points, sizeof(rt_vec3f), h.points, f) == h.points);
+    ok = ok && (!h.texcoords || fwrite(mesh->texcoords, sizeof(rt_vec2f), h.texcoords, f) == h.texcoords);
+    ok = ok && (!h.normals || fwrite(mesh->normals, sizeof(rt_vec3f), h.normals, f) == h.normals);
+    ok = ok && fwrite(mesh->faces, sizeof(rt_triangle), h.faces, f) == h.faces;
+    ok = ok && fwrite(tree, 32, h.nodes, f) == h.nodes;
+    if (f) ok = (fclose(f) == 0) && ok;
+    free(tree);
+    if (!ok) { remove(path); return -3; }
+    return 0;
+}
+
+/* node `*at` of the dump and its subtree back into linked records; 0 on a malformed dump */
+static int restore_node(rt_mesh_node *node, const uint32_t *words, uint32_t count, uint32_t *at, node_pool *pool,
+                        uint32_t faces, uint32_t depth, uint32_t *deepest)
+{
+    if (*at >= count || depth > TREE_DEPTH_LIMIT) return 0;
+    const uint32_t *w = words + 8 * (size_t)(*at)++;
+    memcpy(&node->bbox, w, 24);
+    node->first_triangle_id = w[6];
+    node->last_triangle_id = w[7] & 0x7FFFFFFFu;
+    node->childs = NULL;
+    if (node->first_triangle_id > node->last_triangle_id || node->last_triangle_id >= faces) return 0;
+    if (depth > *deepest) *deepest = depth;
+    if (!(w[7] & 0x80000000u)) return 1;
+    if (pool->used + 2 > pool->cap) return 0;
+    rt_mesh_node *pair = pool->nodes + pool->used;
+    pool->used += 2;
+    node->childs = pair;
+    if (!restore_node(pair + 0, words, count, at, pool, faces, depth + 1, deepest)) return 0;
+    if (!restore_node(pair + 1, words, count, at, pool, faces, depth + 1, deepest)) return 0;
+    /* children split their parent's range */
+    return pair[0].first_triangle_id == node->first_triangle_id && pair[1].last_triangle_id == node->last_triangle_id &&
+           pair[0].last_triangle_id + 1 == pair[1].first_triangle_id;
+}
+
+int rt_host_mesh_load(const char *path, uint64_t key, rt_mesh *out)
+{
+    if (!path || !out) return -1;
+    memset(out, 0, sizeof(*out));
+    FILE *f = fopen(path, "rb");
+    if (!f) return -3;
+    mesh_file_header h;
+    int rc = 0;
+    uint32_t *tree = NULL;
+    node_pool pool = { NULL, 0, 0 };
+    if (fread(&h, sizeof(h), 1, f) != 1 || h.magic != MESH_FILE_MAGIC || h.version != MESH_FILE_VERSION) rc = -4;
+    else if (h.key != key) rc = -7;
+    else if (!h.faces || h.faces > 0x07FFFFFFu || !h.nodes || h.nodes > 2u * h.faces + 1u || !(h.nodes & 1u)) rc = -4;
+    if (!rc) {
+        out->point_count = h.points; out->texcoord_count = h.texcoords; out->normal_count = h.normals; out->face_count = h.faces;
+        out->points = malloc(sizeof(rt_vec3f) * (h.points ? h.points : 1));
+        out->texcoords = malloc(sizeof(rt_vec2f) * (h.texcoords ? h.texcoords : 1));
+        out->normals = malloc(sizeof(rt_vec3f) * (h.normals ? h.normals : 1));
+        out->faces = malloc(sizeof(rt_triangle) * (size_t)h.faces);
+        tree = malloc((size_t)h.nodes * 32);
+        pool.cap = h.nodes; pool.nodes = calloc(pool.cap, sizeof(rt_mesh_node));
+        if (!out->points || !out->texcoords || !out->normals || !out->faces || !tree || !pool.nodes) rc = -2;
+    }
+    if (!rc) {
+        int ok = (!h.points || fread(out->points, sizeof(rt_vec3f), h.points, f) == h.points) &&
+                 (!h.texcoords || fread(out->texcoords, sizeof(rt_vec2f), h.texcoords, f) == h.texcoords) &&
+                 (!h.normals || fread(out->normals, sizeof(rt_vec3f), h.normals, f) == h.normals) &&
+                 fread(out->faces, sizeof(rt_triangle), h.faces, f) == h.faces &&
+                 fread(tree, 32, h.nodes, f) == h.nodes;
+        if (!ok) rc = -4;
+    }
+    if (!rc) {                                       /* indices in range: the file is input, not trusted */
+        for (uint32_t i = 0; i < h.faces && !rc; i++)
+            for (int c = 0; c < 3; c++) {
+                const rt_vertex_ref *v = &out->faces[i].ids[c];
+                if (v->vertexId >= h.points || (h.texcoords && v->texcoordId >= h.texcoords) || (h.normals && v->normalId >= h.normals)) rc = -5;
+            }
+    }
+    if (!rc) {
+        uint32_t at = 0, deepest = 0;
+        if (!restore_node(&out->root, tree, h.nodes, &at, &pool, h.faces, 1, &deepest) || at != h.nodes ||
+            out->root.first_triangle_id != 0 || out->root.last_triangle_id != h.faces - 1 || deepest != h.tree_depth) rc = -4;
+        out->tree_depth = deepest;
+    }
+    fclose(f);
+    free(tree);
+    if (rc) {
+        free(pool.nodes);
+        out->root.childs = NULL;
+        rt_host_mesh_free(out);
+        return rc;
+    }
+    if (!out->root.childs) free(pool.nodes);
+    return 0;
+}
+
 /* 8-bit RGB rows (top row first) -> linear float image stored bottom row
  * first; src/main.c:52-59: powf(byte / 255.0f, 2.2f) per channel. */
 int rt_host_texture_from_rgb8(const uint8_t *rgb, uint32_t width, uint32_t height, rt_image3f *out)

@@ -29,6 +29,10 @@ def lib():
             C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
             C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(T.Mesh)]
         L.rt_host_mesh_from_obj_arrays.restype = C.c_int
+        L.rt_host_mesh_save.argtypes = [C.POINTER(T.Mesh), C.c_uint64, C.c_char_p]
+        L.rt_host_mesh_save.restype = C.c_int
+        L.rt_host_mesh_load.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(T.Mesh)]
+        L.rt_host_mesh_load.restype = C.c_int
         L.rt_host_mesh_free.argtypes = [C.POINTER(T.Mesh)]
         L.rt_host_mesh_free.restype = None
         L.rt_host_mesh_census.argtypes = [C.POINTER(T.Mesh), C.POINTER(C.c_uint32 * 4)]
@@ -69,6 +73,25 @@ def mesh_from_obj_arrays(positions, texcoords, normals, indices_ptn, face_vertic
         rc = lib().rt_host_mesh_build_tree_sah(C.byref(mesh), leaf_triangles)
         if rc != 0:
             raise RuntimeError(f"rt_host_mesh_build_tree_sah failed: {rc}")
+    return mesh
+
+
+def mesh_save(mesh, key, path):
+    """Write a prepared mesh (arrays, permuted faces, tree) to one file under a 64-bit content key."""
+    rc = lib().rt_host_mesh_save(C.byref(mesh), key, os.fsencode(path))
+    if rc != 0:
+        raise RuntimeError(f"rt_host_mesh_save failed: {rc}")
+
+
+def mesh_load(path, key):
+    """A prepared mesh back from its file, or None when the file is missing or was written under another key;
+    a malformed file is an error."""
+    mesh = T.Mesh()
+    rc = lib().rt_host_mesh_load(os.fsencode(path), key, C.byref(mesh))
+    if rc in (-3, -7):
+        return None
+    if rc != 0:
+        raise RuntimeError(f"rt_host_mesh_load({path}) failed: {rc}")
     return mesh
 
 

@@ -122,12 +122,30 @@ _ASSET_CACHE = {}
 
 
 def _load_mesh(name, tree="reference", leaf_triangles=0):
+    """A model's mesh, prepared once per process.  With RT_ASSET_CACHE_DIR set, the prepared mesh (arrays,
+    permuted faces, tree) is also kept there as one file keyed by the model file's digest and the builder's
+    parameters, and later processes map it back instead of parsing and building."""
     key = name if tree == "reference" else f"{name}/{tree}/{leaf_triangles}"
     if key not in _ASSET_CACHE:
-        with np.load(os.path.join(ASSET_DIR, name + "_obj.npz"), allow_pickle=False) as z:
-            _ASSET_CACHE[key] = host.mesh_from_obj_arrays(
-                z["positions"], z["texcoords"], z["normals"], z["indices"], z["face_vertices"],
-                tree=tree, leaf_triangles=leaf_triangles)
+        source = os.path.join(ASSET_DIR, name + "_obj.npz")
+        cache_dir = os.environ.get("RT_ASSET_CACHE_DIR")
+        mesh = path = None
+        if cache_dir:
+            import hashlib
+            with open(source, "rb") as f:
+                digest = hashlib.sha256(f.read() + f"|{tree}|{leaf_triangles}|v1".encode()).digest()
+            content_key = int.from_bytes(digest[:8], "little")
+            path = os.path.join(cache_dir, f"{name}-{tree}-{leaf_triangles}-{digest[:8].hex()}.rtmesh")
+            mesh = host.mesh_load(path, content_key)
+        if mesh is None:
+            with np.load(source, allow_pickle=False) as z:
+                mesh = host.mesh_from_obj_arrays(
+                    z["positions"], z["texcoords"], z["normals"], z["indices"], z["face_vertices"],
+                    tree=tree, leaf_triangles=leaf_triangles)
+            if path:
+                os.makedirs(cache_dir, exist_ok=True)
+                host.mesh_save(mesh, content_key, path)
+        _ASSET_CACHE[key] = mesh
     return _ASSET_CACHE[key]
 
 

@@ -219,3 +219,52 @@ def test_surface_area_tree_on_degenerate_input():
 
 def test_reference_tree_can_be_checked_the_same_way():
     _check_tree(scenes.load_dog_mesh(), 16)
+
+
+def test_prepared_mesh_file_round_trip(tmp_path, monkeypatch):
+    """rt_host_mesh_save / rt_host_mesh_load: the mesh comes back array for array, face for face and node for
+    node (both builders); another key, a missing file, a truncated file and a file with an index out of
+    range are refused; scenes reuse the file through RT_ASSET_CACHE_DIR."""
+    for tree in ("reference", "sah"):
+        mesh = scenes.load_dog_mesh(tree, 8 if tree == "sah" else 0)
+        path = str(tmp_path / f"dog-{tree}.rtmesh")
+        host.mesh_save(mesh, 0x1234_5678_9ABC_DEF0, path)
+        back = host.mesh_load(path, 0x1234_5678_9ABC_DEF0)
+        assert back is not None and back.face_count == mesh.face_count and back.tree_depth == mesh.tree_depth
+        assert (back.point_count, back.texcoord_count, back.normal_count) == (mesh.point_count, mesh.texcoord_count, mesh.normal_count)
+        assert sha(host.mesh_dump_tree(back)) == sha(host.mesh_dump_tree(mesh))
+        assert sha(host.mesh_faces_array(back)) == sha(host.mesh_faces_array(mesh))
+        for attr, n, w in (("points", mesh.point_count, 3), ("texcoords", mesh.texcoord_count, 2), ("normals", mesh.normal_count, 3)):
+            a = np.ctypeslib.as_array(C.cast(getattr(mesh, attr), C.POINTER(C.c_float)), shape=(n, w))
+            b = np.ctypeslib.as_array(C.cast(getattr(back, attr), C.POINTER(C.c_float)), shape=(n, w))
+            assert L.same_bits(a, b).all(), attr
+        host.lib().rt_host_mesh_free(C.byref(back))
+        assert host.mesh_load(path, 0x1234) is None                         # written under another key
+    assert host.mesh_load(str(tmp_path / "absent.rtmesh"), 1) is None
+    data = open(path, "rb").read()
+    cut = str(tmp_path / "cut.rtmesh")
+    open(cut, "wb").write(data[: len(data) // 2])
+    with pytest.raises(RuntimeError, match="-4"):
+        host.mesh_load(cut, 0x1234_5678_9ABC_DEF0)
+    bad = bytearray(data)
+    faces_at = 64 + 12 * mesh.point_count + 8 * mesh.texcoord_count + 12 * mesh.normal_count
+    bad[faces_at:faces_at + 4] = (0x7FFFFFFF).to_bytes(4, "little")         # a vertex index beyond the points
+    open(cut, "wb").write(bytes(bad))
+    with pytest.raises(RuntimeError, match="-5"):
+        host.mesh_load(cut, 0x1234_5678_9ABC_DEF0)
+    bad = bytearray(data)
+    tree_at = faces_at + 36 * mesh.face_count
+    bad[tree_at + 28:tree_at + 32] = (5).to_bytes(4, "little")              # the root claims to be a leaf of triangles 0..5
+    open(cut, "wb").write(bytes(bad))
+    with pytest.raises(RuntimeError, match="-4"):
+        host.mesh_load(cut, 0x1234_5678_9ABC_DEF0)
+    # through the scene helpers: the first call writes the file, a fresh process-level cache reads it back
+    monkeypatch.setenv("RT_ASSET_CACHE_DIR", str(tmp_path / "cache"))
+    monkeypatch.setattr(scenes, "_ASSET_CACHE", {})
+    first = scenes.load_cat_mesh()
+    files = list((tmp_path / "cache").iterdir())
+    assert len(files) == 1 and files[0].suffix == ".rtmesh"
+    monkeypatch.setattr(scenes, "_ASSET_CACHE", {})
+    second = scenes.load_cat_mesh()
+    assert sha(host.mesh_dump_tree(first)) == sha(host.mesh_dump_tree(second))
+    assert sha(host.mesh_faces_array(first)) == sha(host.mesh_faces_array(second))
