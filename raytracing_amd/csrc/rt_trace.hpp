@@ -252,6 +252,8 @@ __device__ __forceinline__ void slab_cached(f3 lo, f3 hi, f3 o, f3 d, f3 y, floa
 /* ball test shared by lights and spheres, src/main.c:283-308 */
 __device__ __forceinline__ bool ball(f3 center, float radius, f3 o, f3 d, float best, float &t_out, bool &entered)
 {
+    /* the early returns stay branches: whole waves miss a ball and skip its square root (a straight-line
+     * form with masks was measured 2 % slower on the launch that starts the paths) */
     f3 oc = sub(o, center);
     float b = dot(d, oc);
     float c = len2(oc) - radius * radius;
@@ -292,6 +294,13 @@ struct Trav {
     bool cached;                 /* the shared-reciprocal slab test is exact for this ray and mesh */
 };
 
+#ifndef RT_SHADOW_EARLY_OUT
+#define RT_SHADOW_EARLY_OUT 0         /* 1: a shadow ray that has found its occluder leaves the primitive loops at once, as the counting
+                                       * builds do (they must count the host's tests).  A lane that leaves early only idles while the
+                                       * rest of its wave goes on, and the branches cost more than they save: without them the launch
+                                       * that starts the paths is 7 % faster; the answer (any hit at all) is the same */
+#endif
+#define RT_EARLY_OUT(stats) (RT_SHADOW_EARLY_OUT || (stats))
 template <bool STATS>
 __device__ __forceinline__ bool query_begin(const rt_dev_scene &S, f3 o, f3 d, float tmax, bool any_hit,
                                             Hit &h, Counters &cn)
@@ -315,7 +324,7 @@ __device__ __forceinline__ bool query_begin(const rt_dev_scene &S, f3 o, f3 d, f
             if (STATS) cn.light_tests++;
             if (ball(c, radius, o, d, h.t, t, h.entered)) {
                 h.type = HIT_LIGHT; h.id = (uint32_t)i; h.t = t;
-                if (any_hit) return true;
+                if (RT_EARLY_OUT(STATS) && any_hit) return true;
             }
             c = c_next; radius = radius_next;
         }
@@ -330,7 +339,7 @@ __device__ __forceinline__ bool query_begin(const rt_dev_scene &S, f3 o, f3 d, f
             if (STATS) cn.sphere_tests++;
             if (ball(c, radius, o, d, h.t, t, h.entered)) {
                 h.type = HIT_SPHERE; h.id = (uint32_t)i; h.t = t; h.material = material;
-                if (any_hit) return true;
+                if (RT_EARLY_OUT(STATS) && any_hit) return true;
             }
             c = c_next; radius = radius_next; material = material_next;
         }
@@ -345,11 +354,12 @@ __device__ __forceinline__ bool query_begin(const rt_dev_scene &S, f3 o, f3 d, f
             const float t = (pd - dot(o, n)) / dot(d, n);
             if (!(t < 1e-3f) && !(t > h.t)) {
                 h.type = HIT_PLANE; h.id = (uint32_t)i; h.t = t; h.material = material;
-                if (any_hit) return true;
+                if (RT_EARLY_OUT(STATS) && any_hit) return true;
             }
             n = n_next; pd = pd_next; material = material_next;
         }
     }
+    if (!RT_EARLY_OUT(STATS) && any_hit && h.type != HIT_NONE) return true;
     return S.instance_count == 0;
 }
 
@@ -1040,9 +1050,17 @@ struct PathMachine {
             float tmax;
             if (event(tmax)) on_end();
             else if (ray != RAY_NONE) {
-                if (!query_begin<STATS>(S, o, d, tmax, ray == RAY_SHADOW, h, cn)) {
+                if (RT_EARLY_OUT(STATS)) {
+                    if (!query_begin<STATS>(S, o, d, tmax, ray == RAY_SHADOW, h, cn)) {
+                        park_inst = query_probe<STATS>(S, o, d, h, 0, cn);
+                        if (park_inst >= 0) phase = PH_PARK;
+                    }
+                } else {
+                    /* the root boxes are tested whether or not the primitives already answered the query: some lane
+                     * of the wave needs the test anyway, and one straight run of code beats a branch around it */
+                    const bool answered = query_begin<STATS>(S, o, d, tmax, ray == RAY_SHADOW, h, cn);
                     park_inst = query_probe<STATS>(S, o, d, h, 0, cn);
-                    if (park_inst >= 0) phase = PH_PARK;
+                    if (!answered && park_inst >= 0) phase = PH_PARK;
                 }
             }
         }
