@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--scene", default="dog_room")
     ap.add_argument("--max-segments", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-measurements", action="store_true",
+                    help="skip the frames rendered beside the benchmark (the surface-area tree): profiling runs count only the benchmark's own launches")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="torch.distributed backend: nccl (= RCCL over xGMI, one GPU per rank); gloo gathers through host "
                          "memory and lets several ranks share a GPU (a functional check of the multi-process path on a "
@@ -370,7 +372,7 @@ def main():
 
     # side measurement, never the headline: the same frame with the opt-in surface-area tree (other boxes, same triangles)
     sah = None
-    if not shared and args.scene in ("dog_room", "three_dogs", "dogs_and_cat"):
+    if not shared and not args.no_side_measurements and args.scene in ("dog_room", "three_dogs", "dogs_and_cat"):
         t1 = time.perf_counter()
         sh2 = scenes.CONFIGS[args.scene](tree="sah", leaf_triangles=8)
         sah_assets_ms = 1e3 * (time.perf_counter() - t1)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/counters.json from rocprofv3 --pmc passes of
-`bench.py --steps 1 --warmup 0 --no-cpu-baseline --frames-in-flight 1`
+`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-side-measurements --frames-in-flight 1`
 (one pass per counter group; tools/profile_round.sh runs them).  That command renders several plain
 frames and one with the detailed counters (kernel instantiations <..., true>, left out here); every
 counter is summed over all launches of a kind and divided by the number of plain frames (= launches
@@ -60,7 +60,7 @@ json.dump({
     "workload": workload,
     "frames_averaged": frames,
     "source": f"profiles/{tag}_pmc_*.csv.gz (raw) and .txt (per-kernel sums): rocprofv3 --pmc, one pass per counter group, of `python3 bench.py --steps 1 --warmup 0 "
-              "--no-cpu-baseline --frames-in-flight 1`; per frame and kind of launch; FETCH_SIZE and WRITE_SIZE in KiB x 1024, raw "
+              "--no-cpu-baseline --no-side-measurements --frames-in-flight 1`; per frame and kind of launch; FETCH_SIZE and WRITE_SIZE in KiB x 1024, raw "
               "(the read counter tallies 128-byte requests at 64 bytes on gfx950: bench.py doubles it)",
     "kinds": kinds,
 }, sys.stdout, indent=1)
