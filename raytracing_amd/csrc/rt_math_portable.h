@@ -42,8 +42,25 @@ __device__ static inline double rt_k_scalar()
     return __hiloint2double((int)hi, (int)lo);
 }
 #define RT_K(c) rt_k_scalar<__builtin_bit_cast(unsigned long long, (double)(c))>()
+/* RT_FMA_K(a, b, c) = fma(a, b, c) with c such a constant.  Left to itself the compiler copies the scalar
+ * pair into two vector registers and uses the two-operand multiply-add that overwrites its addend: three
+ * vector instructions per step of a polynomial.  The three-operand form takes the scalar pair as its
+ * addend directly: one instruction, the same fused operation. */
+template <unsigned long long BITS>
+__device__ static inline double rt_fma_k(double a, double b)
+{
+    unsigned lo, hi;
+    __asm__ volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi)
+                     : "i"((unsigned)(BITS & 0xFFFFFFFFull)), "i"((unsigned)(BITS >> 32)));
+    const unsigned long long k = ((unsigned long long)hi << 32) | (unsigned long long)lo;
+    double r;
+    __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+#define RT_FMA_K(a, b, c) rt_fma_k<__builtin_bit_cast(unsigned long long, (double)(c))>((a), (b))
 #else
 #define RT_K(c) (c)
+#define RT_FMA_K(a, b, c) __builtin_fma((a), (b), (c))
 #endif
 
 /* sine and cosine of a float argument (radians), |x| <= 2^20; NaN beyond.
@@ -65,22 +82,22 @@ RT_MATH_FN void rt_sincosf(float x, float *sin_out, float *cos_out)
     const double y2 = y * y;
 
     double ps = RT_K(1.0 / 1307674368000.0);                                       /* 1/15! */
-    ps = __builtin_fma(ps, y2, RT_K(-1.0 / 6227020800.0));                         /* 1/13! */
-    ps = __builtin_fma(ps, y2, RT_K(1.0 / 39916800.0));
-    ps = __builtin_fma(ps, y2, RT_K(-1.0 / 362880.0));
-    ps = __builtin_fma(ps, y2, RT_K(1.0 / 5040.0));
-    ps = __builtin_fma(ps, y2, RT_K(-1.0 / 120.0));
-    ps = __builtin_fma(ps, y2, RT_K(1.0 / 6.0));
+    ps = RT_FMA_K(ps, y2, -1.0 / 6227020800.0);                         /* 1/13! */
+    ps = RT_FMA_K(ps, y2, 1.0 / 39916800.0);
+    ps = RT_FMA_K(ps, y2, -1.0 / 362880.0);
+    ps = RT_FMA_K(ps, y2, 1.0 / 5040.0);
+    ps = RT_FMA_K(ps, y2, -1.0 / 120.0);
+    ps = RT_FMA_K(ps, y2, 1.0 / 6.0);
     const double y3 = y * y2;
     const double sv = __builtin_fma(-y3, ps, y);                             /* y - y^3 (1/6 - ...) */
 
     double pc = RT_K(1.0 / 20922789888000.0);                                      /* 1/16! */
-    pc = __builtin_fma(pc, y2, RT_K(-1.0 / 87178291200.0));                        /* 1/14! */
-    pc = __builtin_fma(pc, y2, RT_K(1.0 / 479001600.0));
-    pc = __builtin_fma(pc, y2, RT_K(-1.0 / 3628800.0));
-    pc = __builtin_fma(pc, y2, RT_K(1.0 / 40320.0));
-    pc = __builtin_fma(pc, y2, RT_K(-1.0 / 720.0));
-    pc = __builtin_fma(pc, y2, RT_K(1.0 / 24.0));
+    pc = RT_FMA_K(pc, y2, -1.0 / 87178291200.0);                        /* 1/14! */
+    pc = RT_FMA_K(pc, y2, 1.0 / 479001600.0);
+    pc = RT_FMA_K(pc, y2, -1.0 / 3628800.0);
+    pc = RT_FMA_K(pc, y2, 1.0 / 40320.0);
+    pc = RT_FMA_K(pc, y2, -1.0 / 720.0);
+    pc = RT_FMA_K(pc, y2, 1.0 / 24.0);
     pc = __builtin_fma(pc, y2, -0.5);
     const double cv = __builtin_fma(y2, pc, 1.0);
 
@@ -110,16 +127,16 @@ RT_MATH_FN float rt_logf(float x)
     const double s = (m - 1.0) / (m + 1.0);
     const double s2 = s * s;
     double p = RT_K(1.0 / 23.0);
-    p = __builtin_fma(p, s2, RT_K(1.0 / 21.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 19.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 17.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 15.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 13.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 11.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 9.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 7.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 5.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 3.0));
+    p = RT_FMA_K(p, s2, 1.0 / 21.0);
+    p = RT_FMA_K(p, s2, 1.0 / 19.0);
+    p = RT_FMA_K(p, s2, 1.0 / 17.0);
+    p = RT_FMA_K(p, s2, 1.0 / 15.0);
+    p = RT_FMA_K(p, s2, 1.0 / 13.0);
+    p = RT_FMA_K(p, s2, 1.0 / 11.0);
+    p = RT_FMA_K(p, s2, 1.0 / 9.0);
+    p = RT_FMA_K(p, s2, 1.0 / 7.0);
+    p = RT_FMA_K(p, s2, 1.0 / 5.0);
+    p = RT_FMA_K(p, s2, 1.0 / 3.0);
     const double s3 = s * s2;
     const double atanh_s = __builtin_fma(s3, p, s);
     const double two_atanh = atanh_s + atanh_s;
@@ -151,16 +168,16 @@ RT_MATH_FN float rt_gamma_powf(float c)
     const double s = (m - 1.0) / (m + 1.0);
     const double s2 = s * s;
     double p = RT_K(1.0 / 23.0);
-    p = __builtin_fma(p, s2, RT_K(1.0 / 21.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 19.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 17.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 15.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 13.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 11.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 9.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 7.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 5.0));
-    p = __builtin_fma(p, s2, RT_K(1.0 / 3.0));
+    p = RT_FMA_K(p, s2, 1.0 / 21.0);
+    p = RT_FMA_K(p, s2, 1.0 / 19.0);
+    p = RT_FMA_K(p, s2, 1.0 / 17.0);
+    p = RT_FMA_K(p, s2, 1.0 / 15.0);
+    p = RT_FMA_K(p, s2, 1.0 / 13.0);
+    p = RT_FMA_K(p, s2, 1.0 / 11.0);
+    p = RT_FMA_K(p, s2, 1.0 / 9.0);
+    p = RT_FMA_K(p, s2, 1.0 / 7.0);
+    p = RT_FMA_K(p, s2, 1.0 / 5.0);
+    p = RT_FMA_K(p, s2, 1.0 / 3.0);
     const double s3 = s * s2;
     const double atanh_s = __builtin_fma(s3, p, s);
     const double two_atanh = atanh_s + atanh_s;
@@ -171,16 +188,16 @@ RT_MATH_FN float rt_gamma_powf(float c)
     double y = __builtin_fma(-fk, RT_K(6.93147180369123816490e-01), z);
     y = __builtin_fma(-fk, RT_K(1.90821492927058770002e-10), y);
     double q = RT_K(1.0 / 6227020800.0);                                            /* 1/13! */
-    q = __builtin_fma(q, y, RT_K(1.0 / 479001600.0));
-    q = __builtin_fma(q, y, RT_K(1.0 / 39916800.0));
-    q = __builtin_fma(q, y, RT_K(1.0 / 3628800.0));
-    q = __builtin_fma(q, y, RT_K(1.0 / 362880.0));
-    q = __builtin_fma(q, y, RT_K(1.0 / 40320.0));
-    q = __builtin_fma(q, y, RT_K(1.0 / 5040.0));
-    q = __builtin_fma(q, y, RT_K(1.0 / 720.0));
-    q = __builtin_fma(q, y, RT_K(1.0 / 120.0));
-    q = __builtin_fma(q, y, RT_K(1.0 / 24.0));
-    q = __builtin_fma(q, y, RT_K(1.0 / 6.0));
+    q = RT_FMA_K(q, y, 1.0 / 479001600.0);
+    q = RT_FMA_K(q, y, 1.0 / 39916800.0);
+    q = RT_FMA_K(q, y, 1.0 / 3628800.0);
+    q = RT_FMA_K(q, y, 1.0 / 362880.0);
+    q = RT_FMA_K(q, y, 1.0 / 40320.0);
+    q = RT_FMA_K(q, y, 1.0 / 5040.0);
+    q = RT_FMA_K(q, y, 1.0 / 720.0);
+    q = RT_FMA_K(q, y, 1.0 / 120.0);
+    q = RT_FMA_K(q, y, 1.0 / 24.0);
+    q = RT_FMA_K(q, y, 1.0 / 6.0);
     q = __builtin_fma(q, y, 0.5);
     q = __builtin_fma(q, y, 1.0);
     q = __builtin_fma(q, y, 1.0);                                             /* exp(y) */
