@@ -249,6 +249,43 @@ __device__ __forceinline__ void slab_cached(f3 lo, f3 hi, f3 o, f3 d, f3 y, floa
     leave = __builtin_fminf(__builtin_fminf(fx, fy), fz);
 }
 
+/* ---- a box test decided from approximate quotients -------------------------------------
+ *
+ * A slab test is only ever used for comparisons (does the ray enter the box before it leaves it, and before
+ * the closest hit so far), and a correctly rounded division costs eleven instructions where a reciprocal and a
+ * multiply cost two.  The approximate quotient a * rcp(b) lies within 2.5 units in the last place of the host's
+ * a / b, so the approximate entry and exit distances lie within that of the host's; whenever the two sides of a
+ * comparison are further apart than RT_SLAB_MARGIN times their magnitudes (a margin several times the error),
+ * the host's comparison has the same outcome.  Otherwise, and for rays or boxes outside the magnitudes the
+ * bound is proven for, the verdict is "undecided" and the caller makes the host's test by division (a fraction
+ * of a percent of the waves). */
+#ifndef RT_SLAB_APPROX
+#define RT_SLAB_APPROX 1              /* 0: root boxes are always tested by division in the shade kernels */
+#endif
+#define RT_SLAB_MARGIN 4e-6f           /* relative; the error of an approximate distance is below 3e-7 */
+enum : int { BOX_MISSED = 0, BOX_ENTERED = 1, BOX_UNDECIDED = 2 };
+__device__ __forceinline__ bool clearly_apart(float x, float y)
+{
+    return __builtin_fabsf(x - y) > __builtin_fmaf(RT_SLAB_MARGIN, __builtin_fabsf(x), RT_SLAB_MARGIN * __builtin_fabsf(y));
+}
+/* the root test of src/main.c:379-391: entered unless leave < enter or enter > closest */
+__device__ __forceinline__ int root_box_verdict(f3 lo, f3 hi, f3 o, f3 d, float closest)
+{
+    const float ax0 = lo.x - o.x, ay0 = lo.y - o.y, az0 = lo.z - o.z, bx0 = hi.x - o.x, by0 = hi.y - o.y, bz0 = hi.z - o.z;
+    const float dmin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    const float dmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ax0), __builtin_fabsf(ay0)), __builtin_fabsf(az0)),
+                                       __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(bx0), __builtin_fabsf(by0)), __builtin_fabsf(bz0)));
+    /* direction components and numerators of tame magnitude: reciprocals and products are finite, normal or zero */
+    const bool tame_ray = dmin >= 0x1p-40f && dmax <= 0x1p40f && amax <= 0x1p40f;
+    const float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
+    const float ax = ax0 * rx, ay = ay0 * ry, az = az0 * rz, bx = bx0 * rx, by = by0 * ry, bz = bz0 * rz;
+    const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    if (!tame_ray || !clearly_apart(enter, leave) || !clearly_apart(enter, closest)) return BOX_UNDECIDED;
+    return (leave < enter || enter > closest) ? BOX_MISSED : BOX_ENTERED;
+}
+
 /* ball test shared by lights and spheres, src/main.c:283-308 */
 __device__ __forceinline__ bool ball(f3 center, float radius, f3 o, f3 d, float best, float &t_out, bool &entered)
 {
@@ -426,10 +463,23 @@ __device__ __forceinline__ int query_probe(const rt_dev_scene &S, f3 o, f3 d, co
                    ry.x * d.x + ry.y * d.y + ry.z * d.z,
                    rz.x * d.x + rz.y * d.y + rz.z * d.z);
         if (STATS) cn.root_tests++;
+#if RT_SLAB_APPROX
+        const int verdict = root_box_verdict(ld3(m.root_lo), ld3(m.root_hi), mo, mu, h.t);
+        bool entered = verdict == BOX_ENTERED;
+        if (__ballot(verdict == BOX_UNDECIDED)) {            /* some lane is too close to call: the host's test by division */
+            if (verdict == BOX_UNDECIDED) {
+                float enter, leave;
+                slab(ld3(m.root_lo), ld3(m.root_hi), mo, mu, enter, leave);
+                entered = !(leave < enter) && !(enter > h.t);
+            }
+        }
+        if (!entered) continue;
+#else
         float enter, leave;
         slab(ld3(m.root_lo), ld3(m.root_hi), mo, mu, enter, leave);
         if (leave < enter) continue;
         if (enter > h.t) continue;
+#endif
 #if RT_PROBE_ROOT_CHILDREN
         /* The walk of this instance would begin by testing the two boxes under the root (src/main.c:402-447).  A ray
          * that enters neither has nothing to find in the instance: that first step is made here (the root's record
