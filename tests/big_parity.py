@@ -14,8 +14,11 @@ from raytracing_amd import gpu, host, scenes
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 384
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 bad = 0
-for name in sorted(scenes.CONFIGS):
-    sh = scenes.CONFIGS[name]()
+cases = [(name, {}) for name in sorted(scenes.CONFIGS)] + [("dogs_and_cat", dict(tree="sah", leaf_triangles=4))]
+for name, kw in cases:
+    sh = scenes.CONFIGS[name](**kw)
+    if kw:
+        name += " (surface-area tree)"
     gs = gpu.GpuScene(sh)
     img, got = host.new_image(side, side)
     gs.render_region(img, (0, 0, side, side), spp, 77)
