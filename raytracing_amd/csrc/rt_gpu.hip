@@ -87,6 +87,9 @@ __device__ __forceinline__ void flush_counters(const rt::Counters &cn, uint64_t 
 #ifndef RT_TREE_REFILL
 #define RT_TREE_REFILL 16             /* tree kernel: free lanes needed before the wave fetches new rays */
 #endif
+#ifndef RT_TREE_SCAN_MIN
+#define RT_TREE_SCAN_MIN 12           /* tree kernel: lanes waiting to test their next instance's root box that make the test worth running */
+#endif
 #ifndef RT_TREE_BOTH
 #define RT_TREE_BOTH 12               /* tree kernel: lanes that make the minority kind of step worth running too */
 #endif
@@ -596,6 +599,7 @@ rt_tree_kernel(const TreeParams P)
     rt::u32x4 ra = 0, rb = 0, rc = 0, rd = 0;
 #endif
     bool stepped = false;                                /* the lane needs its next record */
+    bool scan_wait = false;                              /* the lane's instance is done (or its ray is new): it waits to test the next instance's root box */
 #if defined(RT_ABLATE_TREE_FETCH)
     uint32_t ablate_word = 0, ab0 = 0, ab1 = 0, ab2 = 0, ab3 = 0;
 #endif
@@ -649,7 +653,7 @@ rt_tree_kernel(const TreeParams P)
                     tv.inst = (int)(e.w & 0xFFFFu) - 1;  /* walk_advance moves on to the instance the ray was parked for */
                     tv.top = -1; tv.tri_cur = 0; tv.tri_end = 0;
                     cur = RT_ENTRY_NONE;
-                    busy = true; stepped = true;
+                    busy = true; scan_wait = true;       /* new rays arrive together: their first root-box test usually runs in this very iteration */
                     if (STATS) cn.root_tests--;          /* the shade kernel already counted this root test */
                 }
             }
@@ -662,8 +666,8 @@ rt_tree_kernel(const TreeParams P)
         RT_TICK(0)
 
         /* ---- node steps by the lane that owns the ray; leaves by the whole wave ------------- */
-        const bool want_tri = busy && !stepped && tv.tri_cur < tv.tri_end;
-        const bool want_node = busy && !stepped && !want_tri;
+        const bool want_tri = busy && !stepped && !scan_wait && tv.tri_cur < tv.tri_end;
+        const bool want_node = busy && !stepped && !scan_wait && !want_tri;
         const unsigned long long tri_mask = __ballot(want_tri);
         const int n_tri = __popcll(tri_mask), n_node = __popcll(__ballot(want_node));
         const bool run_node = n_node > 0 && (n_node >= n_tri || n_node >= RT_TREE_BOTH);
@@ -833,13 +837,28 @@ rt_tree_kernel(const TreeParams P)
 #if RT_TREE_STAGE
         uint32_t want_record = RT_ENTRY_NONE;            /* index of the node record the lane needs next (none) */
 #endif
-        if (stepped) {
-            stepped = false;
+        /* lanes whose instance is done gather before the next instance's root box is tested: the test runs when enough
+         * of them wait, or when the wave has little else to do */
+        bool scan_now = false;
+        {
+            const unsigned long long waiting = __ballot(scan_wait);
+            if (waiting) {
+                if (P.S.instance_count <= 1) scan_now = true;       /* only new rays ever wait, and they come together */
+                else {
+                    const int n_wait = __popcll(waiting), n_other = __popcll(__ballot(busy && !scan_wait));
+                    scan_now = n_wait >= RT_TREE_SCAN_MIN || n_other < RT_TREE_SCAN_MIN;
+                }
+            }
+        }
+        if (stepped || (scan_now && scan_wait)) {
+            const bool may_scan = scan_wait;             /* a lane that has waited tests now; one that just finished its instance waits */
+            stepped = false; scan_wait = false;
             const rt::u32x4 *q = nullptr;
 #if RT_TREE_SPECULATE
             const uint32_t child = cur;                  /* the child the node step turned to (none: the stack or the next instance decide) */
 #endif
-            const int next = rt::walk_advance<STATS>(P.S, o, d, h, tv, stk, cur, q, cn);
+            const int next = rt::walk_advance<STATS>(P.S, o, d, h, tv, stk, cur, q, cn, may_scan);
+            if (next == rt::NEXT_SCAN) scan_wait = true;
             if (next == rt::NEXT_NODE) {
 #if RT_TREE_STAGE
                 want_record = tv.node_base + cur;

@@ -671,13 +671,19 @@ __device__ __forceinline__ int leaf_pair(u32x4 fa, u32x4 fb, u32x4 fc, f3 mo, f3
 /* what the lane does after a step: NEXT_NODE = visit the interior node whose record is at
  * `addr`; NEXT_LEAF = tv.tri_cur..tv.tri_end wait for the wave's next leaf pass; NEXT_DONE = no
  * instance left, the query is answered */
-enum : int { NEXT_DONE = 0, NEXT_NODE = 1, NEXT_LEAF = 2 };
+enum : int { NEXT_DONE = 0, NEXT_NODE = 1, NEXT_LEAF = 2, NEXT_SCAN = 3 };
+/* may_scan = false: a lane whose instance is done and that has further instances to test does not test them
+ * now; it returns NEXT_SCAN unchanged and the caller lets such lanes gather (the test of an instance's root
+ * box -- two table records, a transform, six divisions -- is long, and run for the one or two lanes that
+ * finish an instance in a given step it costs the wave as much as a step of all its lanes) */
 template <bool STATS>
 __device__ __forceinline__ int walk_advance(const rt_dev_scene &S, f3 o, f3 d, const Hit &h, Trav &tv, Stack stk,
-                                            uint32_t &cur, const u32x4 *&addr, Counters &cn)
+                                            uint32_t &cur, const u32x4 *&addr, Counters &cn, bool may_scan = true)
 {
     if (cur == RT_ENTRY_NONE) {
         if (tv.top < 0) {                                /* this instance is done: on to the next one */
+            if (tv.inst + 1 >= S.instance_count) { tv.inst++; return NEXT_DONE; }
+            if (!may_scan) return NEXT_SCAN;
             tv.inst++;
             if (!query_scan<STATS, true>(S, o, d, h, tv, stk, cn)) return NEXT_DONE;
         }
