@@ -2168,6 +2168,7 @@ int rt_gpu_render_jobs(rt_gpu_scene *s, const rt_job *jobs, uint32_t job_count, 
         hipLaunchKernelGGL(rt_render_jobs_kernel<false>, dim3(grid), dim3(RT_BLOCK), lds, nullptr, P);
     e = hipGetLastError();
     if (e0 && e1) { (void)hipEventRecord(e1, nullptr); s->timers.push_back({e0, e1, KIND_FRESH}); }
+    else { if (e0) s->spare_events.push_back(e0); if (e1) s->spare_events.push_back(e1); }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(d_jobs);
     if (e != hipSuccess) return fail(RT_GPU_ERR_DEVICE, std::string("job kernel: ") + hipGetErrorString(e));
