@@ -25,6 +25,13 @@
 #define RT_WAVE 64
 #define RT_PI_D 3.14159265358979323846
 
+/* RT_DOUBLE=n (timing experiment, same pictures): one part of a shade step is computed twice, the second time on
+ * operands the compiler cannot tell are the same; the extra time of a launch is what that part costs where it runs.
+ * 3 sin/cos, 4 lights + spheres + planes, 6 instance root boxes (of the lanes' own steps; a new path's first event is not doubled) */
+#ifndef RT_DOUBLE
+#define RT_DOUBLE 0
+#endif
+#define RT_OPAQUE(x) __asm__ volatile("" : "+v"(x))
 namespace rt {
 
 struct f3 { float x, y, z; };
@@ -969,6 +976,14 @@ struct PathMachine {
         sn = __sinf((float)(2.0 * RT_PI_D * (double)u0)); cs = __cosf((float)(2.0 * RT_PI_D * (double)u0));
 #else
         rt_sincosf((float)(2.0 * RT_PI_D * (double)u0), &sn, &cs);
+#if RT_DOUBLE == 3
+        {
+            float x2 = (float)(2.0 * RT_PI_D * (double)u0), s2, c2;
+            RT_OPAQUE(x2);
+            rt_sincosf(x2, &s2, &c2);
+            if (s2 != sn) { sn = s2; cs = c2; }
+        }
+#endif
 #endif
         float arg;
 #if defined(RT_ABLATE_TRIG)
@@ -1127,7 +1142,22 @@ struct PathMachine {
                     /* the root boxes are tested whether or not the primitives already answered the query: some lane
                      * of the wave needs the test anyway, and one straight run of code beats a branch around it */
                     const bool answered = query_begin<STATS>(S, o, d, tmax, ray == RAY_SHADOW, h, cn);
+#if RT_DOUBLE == 4
+                    {
+                        Hit h2; f3 o2 = o; RT_OPAQUE(o2.x);
+                        (void)query_begin<STATS>(S, o2, d, tmax, ray == RAY_SHADOW, h2, cn);
+                        cn.rays--;
+                        if (h2.t != h.t && h.t == h.t) h = h2;
+                    }
+#endif
                     park_inst = query_probe<STATS>(S, o, d, h, 0, cn);
+#if RT_DOUBLE == 6
+                    {
+                        f3 o2 = o; RT_OPAQUE(o2.x);
+                        const int p2 = query_probe<STATS>(S, o2, d, h, 0, cn);
+                        if (p2 != park_inst) park_inst = p2;
+                    }
+#endif
                     if (!answered && park_inst >= 0) phase = PH_PARK;
                 }
             }
