@@ -364,7 +364,7 @@ def main():
     torch.cuda.synchronize()
     det = g.stats()
     det_kind = g.stats_by_kernel()
-    own_pixels = H * W if by_samples else (H // world) * W
+    own_pixels = H * W if (by_samples or not shared) else len(multi_gpu.rows_of_rank(rank, world, H, band)) * W
     abytes_kind = [algorithmic_bytes(det_kind[k], own_pixels if k == "new_paths" else 0) for k in KINDS]
     abytes = sum(abytes_kind)
     aflops = algorithmic_flops(det)

@@ -22,17 +22,31 @@ def rows_of_rank(rank, world, height, band=BAND_ROWS):
 
 
 def packed_rows(world, height, band=BAND_ROWS):
-    """Rows of every rank's packed buffer; requires an even split so the all-gather is regular."""
-    if height % (band * world):
-        raise ValueError(f"height {height} must be a multiple of band*world = {band * world}")
-    return height // world
+    """Rows of every rank's packed buffer: the bands of the rank with the most bands (the same for all, so that
+    the all-gather is regular; a rank with fewer bands, or a short last band, leaves padding rows).  The same
+    number as rt_gpu_multi_rows_per_rank of the C entry."""
+    bands = (height + band - 1) // band
+    return ((bands + world - 1) // world) * band
+
+
+_ROW_MAPS = {}
 
 
 def assemble(gathered, world, height, width, band=BAND_ROWS):
-    """gathered: tensor (world * height/world, width, 3), the ranks' packed buffers one after the
-    other as all_gather_into_tensor leaves them -> (height, width, 3) in image order."""
-    nb = height // (band * world)
-    return gathered.view(world, nb, band, width, 3).permute(1, 0, 2, 3, 4).reshape(height, width, 3)
+    """gathered: tensor (world * packed_rows, width, 3), the ranks' packed buffers one after the other as
+    all_gather_into_tensor leaves them -> (height, width, 3) in image order.  An even split is a view
+    permutation; otherwise the rows are picked by index (image row y lives in band y // band of rank
+    (y // band) % world, at packed row (y // band // world) * band + y % band)."""
+    if height % (band * world) == 0:
+        nb = height // (band * world)
+        return gathered.view(world, nb, band, width, 3).permute(1, 0, 2, 3, 4).reshape(height, width, 3)
+    import torch
+    key = (world, height, band, str(gathered.device))
+    if key not in _ROW_MAPS:
+        per_rank = packed_rows(world, height, band)
+        rows = [((y // band) % world) * per_rank + (y // band // world) * band + y % band for y in range(height)]
+        _ROW_MAPS[key] = torch.tensor(rows, dtype=torch.long, device=gathered.device)
+    return gathered.index_select(0, _ROW_MAPS[key])
 
 
 # --------------------------------------------------------------------------- split by samples

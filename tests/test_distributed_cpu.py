@@ -31,8 +31,15 @@ def _worker(rank, world, port, width, height, spp, seed, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sh = scenes.sphere_room()
     rows = multi_gpu.rows_of_rank(rank, world, height)
-    assert len(rows) == multi_gpu.packed_rows(world, height)
-    mine = torch.from_numpy(oracle_rows(sh, width, height, rows, spp, seed))
+    per_rank = multi_gpu.packed_rows(world, height)
+    assert len(rows) <= per_rank
+    own = torch.from_numpy(oracle_rows(sh, width, height, rows, spp, seed))
+    mine = torch.full((per_rank,) + tuple(own.shape[1:]), -7.0, dtype=torch.float32)     # padding rows must not reach the frame
+    # a rank's bands sit at multiples of the band height; a short last band leaves the rest of its band empty
+    for k in range(0, len(rows), multi_gpu.BAND_ROWS):
+        band_rows = [y for y in rows if y // multi_gpu.BAND_ROWS == rows[k] // multi_gpu.BAND_ROWS]
+        at = (rows[k] // multi_gpu.BAND_ROWS // world) * multi_gpu.BAND_ROWS
+        mine[at:at + len(band_rows)] = own[k:k + len(band_rows)]
     gathered = torch.zeros((world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=torch.float32)
     dist.all_gather_into_tensor(gathered, mine)
     frame = multi_gpu.assemble(gathered, world, height, width).numpy().copy()
@@ -41,9 +48,12 @@ def _worker(rank, world, port, width, height, spp, seed, q):
     q.put((rank, frame))
 
 
-def test_band_split_all_gather_two_ranks():
+@pytest.mark.parametrize("world,height", [(2, 32), (3, 44)])
+def test_band_split_all_gather(world, height):
+    """two ranks with an even split (the assembly is a view permutation) and three ranks over a height that
+    is no multiple of anything (ragged last band, a rank with one band fewer: assembly by row index)"""
     import torch.multiprocessing as mp
-    width, height, spp, seed, world = 24, 32, 2, 77, 2
+    width, spp, seed = 24, 2, 77
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -68,8 +78,12 @@ def test_rows_of_rank_partition():
             seen = sorted(y for r in range(world) for y in multi_gpu.rows_of_rank(r, world, height))
             assert seen == list(range(height))
             assert all(len(multi_gpu.rows_of_rank(r, world, height)) == height // world for r in range(world))
-    with pytest.raises(ValueError):
-        multi_gpu.packed_rows(3, 64)
+            assert multi_gpu.packed_rows(world, height) == height // world
+    for world, height, want in ((3, 64, 24), (3, 61, 24), (5, 8, 8), (8, 4096 + 3, 520)):
+        seen = sorted(y for r in range(world) for y in multi_gpu.rows_of_rank(r, world, height))
+        assert seen == list(range(height))
+        assert multi_gpu.packed_rows(world, height) == want
+        assert max(len(multi_gpu.rows_of_rank(r, world, height)) for r in range(world)) <= want
 
 
 def _sum_worker(rank, world, port, q):
