@@ -528,11 +528,160 @@ struct TreeParams {
                                        * (the owners' reads of their records then fall on different LDS banks) */
 #define RT_STAGE_WORDS_PER_WAVE (RT_TREE_STAGE ? 4u * RT_STAGE_LOAD_WORDS : 0u)
 #define RT_TREE_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * (RT_LEAF_WORDS_PER_WAVE + RT_STAGE_WORDS_PER_WAVE) * 4u + (size_t)RT_TREE_TOP * 64u)   /* bytes per workgroup for the leaf passes, the staged node records and the tree tops */
+#ifndef RT_FINISH_SPARSE
+#define RT_FINISH_SPARSE 12       /* finish kernel: a wave with at most this many paths runs every kind of step in each iteration */
+#endif
+#define RT_FINISH_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * RT_LEAF_WORDS_PER_WAVE * 4u)   /* the finish kernel's leaf passes */
 #if RT_TREE_WAVES
 #define RT_TREE_ATTR __attribute__((amdgpu_waves_per_eu(RT_TREE_WAVES, RT_TREE_WAVES)))
 #else
 #define RT_TREE_ATTR
 #endif
+
+/* ---- a leaf pass: the pending leaf triangles of all rays of the wave, 64 (ray, triangle) pairs per step ----
+ * want_tri lanes hold a ray with an open leaf (tv.tri_cur < tv.tri_end); every lane of the wave must call.  Tests
+ * the leaf's remaining triangles against the ray exactly as one query_tri_step per triangle would (src/main.c:449-482),
+ * leaves the result in h and closes the leaf.  Returns whether a triangle was accepted (an any-hit ray is then done).
+ * leaf_best: 64 keys, leaf_marks: 32 words, leaf_bary: 128 floats of the wave's own LDS. */
+template <bool STATS>
+__device__ __forceinline__ bool wave_leaf_pass(const rt_dev_scene &S, const bool want_tri, const unsigned long long tri_mask,
+                                               const bool any_hit, rt::Hit &h, rt::Trav &tv, const uint32_t lane,
+                                               const unsigned long long lanes_below, unsigned long long *leaf_best,
+                                               uint32_t *leaf_marks, float *leaf_bary, rt::Counters &cn)
+{
+    (void)leaf_marks; (void)leaf_bary;
+    const int n_tri = __popcll(tri_mask);
+    bool accepted = false;
+    /* pairs are numbered ray by ray: ray of lane l owns pairs first..first+count-1 */
+    const uint32_t count = want_tri ? tv.tri_end - tv.tri_cur : 0u;
+    /* running sum over the 64 lanes by lane-shifted adds inside the vector unit (rows of 16, then the row
+     * totals carried on): six instructions and no trip through the LDS crossbar, whose latency a scan by
+     * lane exchange pays six times in a row */
+    uint32_t incl = count;
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);    /* row_shr:1 */
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);    /* row_shr:2 */
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);    /* row_shr:4 */
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);    /* row_shr:8 */
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);    /* row_bcast:15 into rows 1 and 3 */
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);    /* row_bcast:31 into rows 2 and 3 */
+    const uint32_t first = incl - count;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    /* owners packed to the low lanes in lane order (= order of their first pairs): packed owner i is
+     * the i-th ray with pairs */
+    const uint32_t dest = want_tri ? (uint32_t)__popcll(tri_mask & lanes_below)
+                                   : (uint32_t)n_tri + (uint32_t)__popcll(~tri_mask & lanes_below);
+    const uint32_t packed_lane = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest * 4u), (int)lane);
+#if RT_LEAF_MARKS
+    /* which ray owns pair k: the rays mark their first pairs in a bit table (at most 64 x 16 pairs); the 64 bits
+     * of a step's pairs number the owners: no search */
+    if (lane < 32u) leaf_marks[lane] = 0u;
+    if (want_tri) __hip_atomic_fetch_or(leaf_marks + (first >> 5), 1u << (first & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t owners_before = 0;
+#else
+    const uint32_t packed_first = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest * 4u), want_tri ? (int)first : -1);
+#endif
+    unsigned long long *best = leaf_best + lane;     /* this lane's slot as an owner */
+    /* closest-hit rays: key = bits of t << 32 | (0xFFFFFFFE - place): smallest t, ties to the later triangle.
+     * any-hit rays stop at the first accepted triangle: key = place << 32 | bits of t.  0 = walk one by one. */
+    if (want_tri) *best = (h.t != h.t) ? 0ull
+                        : any_hit ? ~0ull : (((unsigned long long)__float_as_uint(h.t) << 32) | 0xFFFFFFFFull);
+    const uint32_t tri_first = (tv.tri_base + tv.tri_cur) | (any_hit ? 0x80000000u : 0u);
+    for (uint32_t base = 0; base < total; base += 64u) {
+        const uint32_t k = base + lane;
+#if RT_LEAF_MARKS
+        const uint32_t starts_lo = leaf_marks[base >> 5], starts_hi = leaf_marks[(base >> 5) + 1u];   /* the same words for every lane */
+        const unsigned long long upto = lanes_below | (1ull << lane);
+        const uint32_t pos = owners_before + (uint32_t)__popc(starts_lo & (uint32_t)upto) + (uint32_t)__popc(starts_hi & (uint32_t)(upto >> 32)) - 1u;
+        owners_before += (uint32_t)__popc(starts_lo) + (uint32_t)__popc(starts_hi);
+#else
+        uint32_t pos = 0;                            /* last packed owner whose first pair is <= k */
+        for (uint32_t step = 32u; step; step >>= 1) {
+            const uint32_t probe = pos + step;
+            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(probe * 4u), (int)packed_first);
+            if (v <= k) pos = probe;
+        }
+#endif
+        const uint32_t owner = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos * 4u), (int)packed_lane);
+        const int from = (int)(owner * 4u);
+        const uint32_t own_first = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)first);
+        const uint32_t own_word = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)tri_first);
+        const uint32_t own_tri = own_word & 0x7FFFFFFFu;
+        const bool own_any = (own_word >> 31) != 0u;
+        rt::f3 mo, mu;
+        mo.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mo.x)));
+        mo.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mo.y)));
+        mo.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mo.z)));
+        mu.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mu.x)));
+        mu.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mu.y)));
+        mu.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mu.z)));
+        const float entry_t = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(h.t)));
+        if (STATS) { if (lane == 0) cn.tri_steps++; if (k < total) cn.tri_lanes++; }
+        if (k < total) {
+            const uint32_t place = k - own_first;    /* position in the leaf's remaining triangles */
+            const rt::u32x4 *q = reinterpret_cast<const rt::u32x4 *>(S.tris + own_tri + place);
+            const rt::u32x4 fa = q[0], fb = q[1], fc = q[2];
+            float t, beta, gamma;
+            if (STATS && !own_any) cn.tri_tests++;   /* an any-hit ray counts its tests when it reads its result */
+            const int verdict = rt::leaf_pair(fa, fb, fc, mo, mu, entry_t, t, beta, gamma);
+            if (verdict != rt::PAIR_REJECTED) {
+                unsigned long long *slot_best = leaf_best + owner;
+                const unsigned long long key = verdict == rt::PAIR_UNORDERED ? 0ull
+                    : own_any ? (((unsigned long long)place << 32) | (unsigned long long)__float_as_uint(t))
+                              : (((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(0xFFFFFFFEu - place));
+#if RT_LEAF_REDO
+                __hip_atomic_fetch_min(slot_best, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   /* result unused: no wait */
+#else
+                atomicMin(slot_best, key);
+                /* a minimum with all-ones changes nothing and returns the slot as an LDS operation, in order behind
+                 * the wave's updates above */
+                if (key && atomicMin(slot_best, ~0ull) == key) {                 /* best so far: leave the barycentrics */
+                    leaf_bary[2 * owner] = beta; leaf_bary[2 * owner + 1] = gamma;
+                }
+#endif
+            }
+        }
+    }
+    if (want_tri) {
+        const unsigned long long key = atomicMin(best, ~0ull);
+        uint32_t place = 0;
+        if (key == 0ull) {                           /* unordered distance somewhere: the host's one-by-one walk */
+            while (tv.tri_cur < tv.tri_end) {
+                const int r = rt::query_tri_step<STATS>(S, any_hit, h, tv, cn);
+                if (STATS && !any_hit) cn.tri_tests--;   /* counted by the pass above */
+                if (r == rt::STEP_QUERY_DONE) { accepted = true; break; }   /* only an any-hit ray needs to know */
+            }
+        } else if (any_hit) {
+            const uint32_t count_here = tv.tri_end - tv.tri_cur;
+            if (key != ~0ull) {
+                place = (uint32_t)(key >> 32);
+                h.type = rt::HIT_TRIANGLE; h.t = __uint_as_float((uint32_t)key);
+                h.id = tv.tri_cur + place; h.inst = (uint32_t)tv.inst;
+                h.material = tv.material;
+                accepted = true;
+                if (STATS) cn.tri_tests += place + 1u;   /* the host stops at this triangle */
+            } else if (STATS) cn.tri_tests += count_here;
+        } else if ((uint32_t)key != 0xFFFFFFFFu) {
+            place = 0xFFFFFFFEu - (uint32_t)key;
+            h.type = rt::HIT_TRIANGLE; h.t = __uint_as_float((uint32_t)(key >> 32));
+            h.id = tv.tri_cur + place; h.inst = (uint32_t)tv.inst;
+            h.material = tv.material;
+            accepted = true;
+        }
+        if (accepted && key != 0ull) {
+#if RT_LEAF_REDO
+            /* the winner's barycentrics: the same operations on the same operands again give the same bits
+             * (cheaper than a second pass of LDS traffic for every pair, since few leaf visits end in a hit) */
+            const rt::u32x4 *q = reinterpret_cast<const rt::u32x4 *>(S.tris + tv.tri_base + tv.tri_cur + place);
+            float t2;
+            (void)rt::leaf_pair(q[0], q[1], q[2], tv.mo, tv.mu, 3.402823466e+38f, t2, h.beta, h.gamma);
+#else
+            h.beta = leaf_bary[2 * lane]; h.gamma = leaf_bary[2 * lane + 1];
+#endif
+        }
+        tv.tri_cur = tv.tri_end;
+    }
+    return accepted;
+}
 
 template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) RT_TREE_ATTR
@@ -675,134 +824,8 @@ rt_tree_kernel(const TreeParams P)
         /* the leaf pass goes first: the node records requested at the end of the previous iteration
          * have its whole duration to arrive */
         if (run_leaf) {
-            /* pairs are numbered ray by ray: ray of lane l owns pairs first..first+count-1 */
-            const uint32_t count = want_tri ? tv.tri_end - tv.tri_cur : 0u;
-            /* running sum over the 64 lanes by lane-shifted adds inside the vector unit (rows of 16, then the row
-             * totals carried on): six instructions and no trip through the LDS crossbar, whose latency a scan by
-             * lane exchange pays six times in a row */
-            uint32_t incl = count;
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);    /* row_shr:1 */
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);    /* row_shr:2 */
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);    /* row_shr:4 */
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);    /* row_shr:8 */
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);    /* row_bcast:15 into rows 1 and 3 */
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);    /* row_bcast:31 into rows 2 and 3 */
-            const uint32_t first = incl - count;
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            /* owners packed to the low lanes in lane order (= order of their first pairs): packed owner i is
-             * the i-th ray with pairs */
-            const uint32_t dest = want_tri ? (uint32_t)__popcll(tri_mask & lanes_below)
-                                           : (uint32_t)n_tri + (uint32_t)__popcll(~tri_mask & lanes_below);
-            const uint32_t packed_lane = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest * 4u), (int)lane);
-#if RT_LEAF_MARKS
-            /* which ray owns pair k: the rays mark their first pairs in a bit table (at most 64 x 16 pairs); the 64 bits
-             * of a step's pairs number the owners: no search */
-            if (lane < 32u) leaf_marks[lane] = 0u;
-            if (want_tri) __hip_atomic_fetch_or(leaf_marks + (first >> 5), 1u << (first & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            uint32_t owners_before = 0;
-#else
-            const uint32_t packed_first = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest * 4u), want_tri ? (int)first : -1);
-#endif
-            unsigned long long *best = leaf_best + lane;     /* this lane's slot as an owner */
-            /* closest-hit rays: key = bits of t << 32 | (0xFFFFFFFE - place): smallest t, ties to the later triangle.
-             * any-hit rays stop at the first accepted triangle: key = place << 32 | bits of t.  0 = walk one by one. */
-            if (want_tri) *best = (h.t != h.t) ? 0ull
-                                : any_hit ? ~0ull : (((unsigned long long)__float_as_uint(h.t) << 32) | 0xFFFFFFFFull);
-            const uint32_t tri_first = (tv.tri_base + tv.tri_cur) | (any_hit ? 0x80000000u : 0u);
-            for (uint32_t base = 0; base < total; base += 64u) {
-                const uint32_t k = base + lane;
-#if RT_LEAF_MARKS
-                const uint32_t starts_lo = leaf_marks[base >> 5], starts_hi = leaf_marks[(base >> 5) + 1u];   /* the same words for every lane */
-                const unsigned long long upto = lanes_below | (1ull << lane);
-                const uint32_t pos = owners_before + (uint32_t)__popc(starts_lo & (uint32_t)upto) + (uint32_t)__popc(starts_hi & (uint32_t)(upto >> 32)) - 1u;
-                owners_before += (uint32_t)__popc(starts_lo) + (uint32_t)__popc(starts_hi);
-#else
-                uint32_t pos = 0;                            /* last packed owner whose first pair is <= k */
-                for (uint32_t step = 32u; step; step >>= 1) {
-                    const uint32_t probe = pos + step;
-                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(probe * 4u), (int)packed_first);
-                    if (v <= k) pos = probe;
-                }
-#endif
-                const uint32_t owner = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos * 4u), (int)packed_lane);
-                const int from = (int)(owner * 4u);
-                const uint32_t own_first = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)first);
-                const uint32_t own_word = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)tri_first);
-                const uint32_t own_tri = own_word & 0x7FFFFFFFu;
-                const bool own_any = (own_word >> 31) != 0u;
-                rt::f3 mo, mu;
-                mo.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mo.x)));
-                mo.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mo.y)));
-                mo.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mo.z)));
-                mu.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mu.x)));
-                mu.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mu.y)));
-                mu.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(tv.mu.z)));
-                const float entry_t = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(h.t)));
-                if (STATS) { if (lane == 0) cn.tri_steps++; if (k < total) cn.tri_lanes++; }
-                if (k < total) {
-                    const uint32_t place = k - own_first;    /* position in the leaf's remaining triangles */
-                    const rt::u32x4 *q = reinterpret_cast<const rt::u32x4 *>(P.S.tris + own_tri + place);
-                    const rt::u32x4 fa = q[0], fb = q[1], fc = q[2];
-                    float t, beta, gamma;
-                    if (STATS && !own_any) cn.tri_tests++;   /* an any-hit ray counts its tests when it reads its result */
-                    const int verdict = rt::leaf_pair(fa, fb, fc, mo, mu, entry_t, t, beta, gamma);
-                    if (verdict != rt::PAIR_REJECTED) {
-                        unsigned long long *slot_best = leaf_best + owner;
-                        const unsigned long long key = verdict == rt::PAIR_UNORDERED ? 0ull
-                            : own_any ? (((unsigned long long)place << 32) | (unsigned long long)__float_as_uint(t))
-                                      : (((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(0xFFFFFFFEu - place));
-#if RT_LEAF_REDO
-                        __hip_atomic_fetch_min(slot_best, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   /* result unused: no wait */
-#else
-                        atomicMin(slot_best, key);
-                        /* a minimum with all-ones changes nothing and returns the slot as an LDS operation, in order behind
-                         * the wave's updates above */
-                        if (key && atomicMin(slot_best, ~0ull) == key) {                 /* best so far: leave the barycentrics */
-                            leaf_bary[2 * owner] = beta; leaf_bary[2 * owner + 1] = gamma;
-                        }
-#endif
-                    }
-                }
-            }
+            const bool accepted = wave_leaf_pass<STATS>(P.S, want_tri, tri_mask, any_hit, h, tv, lane, lanes_below, leaf_best, leaf_marks, leaf_bary, cn);
             if (want_tri) {
-                const unsigned long long key = atomicMin(best, ~0ull);
-                bool accepted = false;
-                uint32_t place = 0;
-                if (key == 0ull) {                           /* unordered distance somewhere: the host's one-by-one walk */
-                    while (tv.tri_cur < tv.tri_end) {
-                        const int r = rt::query_tri_step<STATS>(P.S, any_hit, h, tv, cn);
-                        if (STATS && !any_hit) cn.tri_tests--;   /* counted by the pass above */
-                        if (r == rt::STEP_QUERY_DONE) { accepted = true; break; }   /* only an any-hit ray needs to know */
-                    }
-                } else if (any_hit) {
-                    const uint32_t count_here = tv.tri_end - tv.tri_cur;
-                    if (key != ~0ull) {
-                        place = (uint32_t)(key >> 32);
-                        h.type = rt::HIT_TRIANGLE; h.t = __uint_as_float((uint32_t)key);
-                        h.id = tv.tri_cur + place; h.inst = (uint32_t)tv.inst;
-                        h.material = tv.material;
-                        accepted = true;
-                        if (STATS) cn.tri_tests += place + 1u;   /* the host stops at this triangle */
-                    } else if (STATS) cn.tri_tests += count_here;
-                } else if ((uint32_t)key != 0xFFFFFFFFu) {
-                    place = 0xFFFFFFFEu - (uint32_t)key;
-                    h.type = rt::HIT_TRIANGLE; h.t = __uint_as_float((uint32_t)(key >> 32));
-                    h.id = tv.tri_cur + place; h.inst = (uint32_t)tv.inst;
-                    h.material = tv.material;
-                    accepted = true;
-                }
-                if (accepted && key != 0ull) {
-#if RT_LEAF_REDO
-                    /* the winner's barycentrics: the same operations on the same operands again give the same bits
-                     * (cheaper than a second pass of LDS traffic for every pair, since few leaf visits end in a hit) */
-                    const rt::u32x4 *q = reinterpret_cast<const rt::u32x4 *>(P.S.tris + tv.tri_base + tv.tri_cur + place);
-                    float t2;
-                    (void)rt::leaf_pair(q[0], q[1], q[2], tv.mo, tv.mu, 3.402823466e+38f, t2, h.beta, h.gamma);
-#else
-                    h.beta = leaf_bary[2 * lane]; h.gamma = leaf_bary[2 * lane + 1];
-#endif
-                }
-                tv.tri_cur = tv.tri_end;
                 stepped = true;
                 if (accepted && any_hit) { finish(); stepped = false; }
             }
@@ -969,37 +992,75 @@ rt_finish_kernel(const FinishParams P)
     uint32_t in_cur = 0, in_end = 0;
     bool input_done = false;
     pm.phase = rt::PH_DEAD;
-    pm.run(RT_SHADE_WEIGHT,
-        [&]() {                                          /* a path ended */
-            const rt::f3 c = pm.path_value();
-            float *dst = P.samples + 3 * (size_t)sample_index;
-            dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
-            pm.phase = rt::PH_DEAD;
-        },
-        [&]() {                                          /* free lanes take the next records, a quarter wave at a time */
-            while (!input_done) {
-                const unsigned long long need = __ballot(pm.phase == rt::PH_DEAD);
-                if (__popcll(need) < 16) break;
-                if (in_cur >= in_end) {
-                    uint32_t v = 0;
-                    if (lane == 0) v = atomicAdd(&q->in_next, 64u);
-                    in_cur = __builtin_amdgcn_readfirstlane(v);
-                    if (in_cur >= slots) { input_done = true; break; }
-                    in_end = in_cur + 64u < slots ? in_cur + 64u : slots;
-                }
-                const uint32_t idx = in_cur + (uint32_t)__popcll(need & lanes_below);
-                if (pm.phase == rt::PH_DEAD && idx < in_end &&
-                    pm.load_record(list + (size_t)idx * RT_RECORD_WORDS, sample_index)) {
-                    if (!(list[(size_t)idx * RT_RECORD_WORDS] & 0x80u)) {   /* the query still has a tree to walk */
-                        pm.tv.inst = (int)(list[(size_t)idx * RT_RECORD_WORDS + 15] & 0xFFFFu);   /* instance the ray was parked for */
-                        pm.phase = rt::PH_SCAN;
-                        if (STATS) cn.root_tests--;      /* counted when the ray was parked */
-                    }
-                }
-                in_cur += (uint32_t)__popcll(need);
-                if (in_cur > in_end) in_cur = in_end;
+    /* after the stacks: the wave's area for the leaf passes, as in the tree kernel */
+    uint32_t *leaf_area = lds + (size_t)RT_BLOCK * P.S.stack_cap + (threadIdx.x >> 6) * RT_LEAF_WORDS_PER_WAVE;
+    unsigned long long *leaf_best = reinterpret_cast<unsigned long long *>(leaf_area);
+    uint32_t *leaf_marks = leaf_area + 128;
+    float *leaf_bary = reinterpret_cast<float *>(leaf_area + 128 + (RT_LEAF_MARKS ? 32 : 0));
+    auto on_end = [&]() {                                /* a path ended */
+        const rt::f3 c = pm.path_value();
+        float *dst = P.samples + 3 * (size_t)sample_index;
+        dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
+        pm.phase = rt::PH_DEAD;
+    };
+    /* The in-wave scheduler of PathMachine::run with one change: an open leaf is tested by the whole wave at once
+     * (this kernel's waves run with few paths, and its duration is the longest path's chain of steps: a leaf of
+     * sixteen triangles is one step of that chain instead of sixteen). */
+    for (;;) {
+        /* free lanes take the next records, a quarter wave at a time */
+        while (!input_done) {
+            const unsigned long long need = __ballot(pm.phase == rt::PH_DEAD);
+            if (__popcll(need) < 16) break;
+            if (in_cur >= in_end) {
+                uint32_t v = 0;
+                if (lane == 0) v = atomicAdd(&q->in_next, 64u);
+                in_cur = __builtin_amdgcn_readfirstlane(v);
+                if (in_cur >= slots) { input_done = true; break; }
+                in_end = in_cur + 64u < slots ? in_cur + 64u : slots;
             }
-        });
+            const uint32_t idx = in_cur + (uint32_t)__popcll(need & lanes_below);
+            if (pm.phase == rt::PH_DEAD && idx < in_end &&
+                pm.load_record(list + (size_t)idx * RT_RECORD_WORDS, sample_index)) {
+                if (!(list[(size_t)idx * RT_RECORD_WORDS] & 0x80u)) {   /* the query still has a tree to walk */
+                    pm.tv.inst = (int)(list[(size_t)idx * RT_RECORD_WORDS + 15] & 0xFFFFu);   /* instance the ray was parked for */
+                    pm.phase = rt::PH_SCAN;
+                    if (STATS) cn.root_tests--;          /* counted when the ray was parked */
+                }
+            }
+            in_cur += (uint32_t)__popcll(need);
+            if (in_cur > in_end) in_cur = in_end;
+        }
+        const int n_shade = __popcll(__ballot(pm.wants_shade()));
+        const int n_tri = __popcll(__ballot(pm.wants_tri()));
+        const int n_pop = __popcll(__ballot(pm.wants_pop()));
+        if (!(n_shade | n_tri | n_pop)) break;
+        /* a full wave runs the kind of step most lanes want (a shade step is long, so it should run fuller);
+         * a wave with few paths left runs every kind in turn, so that each path moves on in every iteration
+         * (pop, then the leaf it opened, then the shading of the answer) */
+        const bool sparse = n_shade + n_tri + n_pop <= RT_FINISH_SPARSE;
+        const int s_shade = n_shade * RT_SHADE_WEIGHT;           /* weights in 1/16ths */
+        const int s_tri = n_tri * 16, s_pop = n_pop * 16;
+        const bool vote_shade = s_shade >= s_tri && s_shade >= s_pop;
+        const bool vote_pop = !vote_shade && s_pop >= s_tri;
+        if (sparse ? n_pop > 0 : vote_pop) {
+            if (STATS) { if (lane == 0) cn.pop_steps++; if (pm.wants_pop()) cn.pop_lanes++; }
+            if (pm.wants_pop()) pm.after_tree(rt::query_pop_step<STATS>(P.S, pm.h, pm.tv, stk, cn));
+        }
+        if (sparse || !(vote_shade || vote_pop)) {
+            const bool want_tri = pm.wants_tri();
+            const unsigned long long tri_mask = __ballot(want_tri);
+            if (tri_mask) {
+                const bool any_hit = pm.ray == rt::RAY_SHADOW;
+                const bool accepted = wave_leaf_pass<STATS>(P.S, want_tri, tri_mask, any_hit, pm.h, pm.tv, lane, lanes_below,
+                                                            leaf_best, leaf_marks, leaf_bary, cn);
+                if (want_tri && accepted && any_hit) pm.after_tree(rt::STEP_QUERY_DONE);
+            }
+        }
+        if (sparse ? __ballot(pm.wants_shade()) != 0ull : vote_shade) {
+            if (STATS) { if (lane == 0) cn.shade_steps++; if (pm.wants_shade()) cn.shade_lanes++; }
+            pm.shade_step(on_end);
+        }
+    }
     flush_counters<STATS>(cn, P.stats);
 }
 
@@ -1520,7 +1581,7 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, rt_shade_kernel<true, false, true>, RT_BLOCK, RT_POOL_LDS) != hipSuccess || per_cu_shade < 1) per_cu_shade = 1;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tree, rt_tree_kernel<false>, RT_BLOCK, lds_bytes + RT_TREE_EXTRA_LDS) != hipSuccess || per_cu_tree < 1) per_cu_tree = 1;
             int per_cu_finish = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_finish, rt_finish_kernel<false, true>, RT_BLOCK, lds_bytes) != hipSuccess || per_cu_finish < 1) per_cu_finish = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_finish, rt_finish_kernel<false, true>, RT_BLOCK, lds_bytes + RT_FINISH_EXTRA_LDS) != hipSuccess || per_cu_finish < 1) per_cu_finish = 1;
             s->finish_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_finish);
             int per_cu_resume = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_resume, rt_shade_kernel<false, false, true>, RT_BLOCK, RT_STAGE_LDS) != hipSuccess || per_cu_resume < 1) per_cu_resume = 1;
@@ -1840,11 +1901,12 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
 
     const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
     const uint32_t resolve_grid = (uint32_t)((units * 64 + RT_BLOCK - 1) / RT_BLOCK);
-    /* parked records at or below which one launch finishes the paths: 1/128 of the batch's paths, within
-     * [65536, 262144] (the finishing launch runs few lanes per wave, so a small batch must not leave it much) */
-    uint64_t finish_paths = batch_spp * items_per_sample / 128;
+    /* parked records at or below which one launch finishes the paths: 1/64 of the batch's paths, within
+     * [65536, 1048576] (the finishing launch runs few lanes per wave, so a small batch must not leave it much;
+     * measured on three scenes at 1024x1024x64: a frame is shortest with about a million) */
+    uint64_t finish_paths = batch_spp * items_per_sample / 64;
     if (finish_paths < 65536) finish_paths = 65536;
-    if (finish_paths > 262144) finish_paths = 262144;
+    if (finish_paths > 1048576) finish_paths = 1048576;
     const uint32_t finish_below = K.finish_below >= 0 ? (uint32_t)K.finish_below : (uint32_t)finish_paths;
     /* a wave that has no input left and fewer paths than this hands them to the next round; needs the
      * finishing launch to end the batch (without it the rounds run to the last path themselves) */
@@ -1898,7 +1960,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
             F.totals = s->d_stats + RT_KINDS * RT_STAT_WORDS;
             F.samples = P.samples; F.stats = s->d_stats + KIND_FINISH * RT_STAT_WORDS;
             F.seed0 = P.seed0; F.seed1 = P.seed1; F.max_segments = P.max_segments; F.half_w = P.half_w; F.half_h = P.half_h;
-            if ((rc = timed_launch(s, timed, KIND_FINISH, stream, [&]() { launch_finish(detailed, s->specular, s->finish_blocks, lds, stream, F); }))) return rc;
+            if ((rc = timed_launch(s, timed, KIND_FINISH, stream, [&]() { launch_finish(detailed, s->specular, s->finish_blocks, lds + RT_FINISH_EXTRA_LDS, stream, F); }))) return rc;
         }
 
         if (previous_sum) RT_HIP(hipStreamWaitEvent(stream, previous_sum, 0));
@@ -2028,7 +2090,7 @@ int rt_gpu_render_region_static(rt_gpu_scene *s, float *device_pixels, uint32_t 
     uint32_t fgrid = (uint32_t)((paths + 8192u + 255u) / 256u);      /* a workgroup per 256 slots that can hold a record */
     if (fgrid > s->finish_blocks) fgrid = s->finish_blocks;
     const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
-    launch_finish(detailed, s->specular, fgrid, lds, stream, F);
+    launch_finish(detailed, s->specular, fgrid, lds + RT_FINISH_EXTRA_LDS, stream, F);
     RT_HIP(hipGetLastError());
 
     ResolveParams R;
