@@ -945,6 +945,9 @@ rt_tree_kernel(const TreeParams P)
  * floor of some 50 us and ends with its slowest ray).  This kernel takes the parked, not yet
  * answered records and runs each path to its end with the in-wave scheduler: shade, node and
  * triangle steps by ballot, trees walked by the lane itself. */
+#if defined(RT_FINISH_CLOCKS)    /* experiment: where the longest-running wave of the finishing launch spends its time */
+__device__ unsigned long long rt_finish_clock_max;
+#endif
 struct FinishParams {
     rt_dev_scene S;
     const uint32_t *lists[2];        /* round r parked into lists[r & 1] */
@@ -984,7 +987,7 @@ rt_finish_kernel(const FinishParams P)
     rt::Stack stk; stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK;
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
     const uint32_t lane = threadIdx.x & 63;
-    rt::PathMachine<rt::CounterRng, STATS, SPECULAR> pm(P.S, stk, cn);
+    rt::PathMachine<rt::CounterRng, STATS, SPECULAR, true> pm(P.S, stk, cn);   /* box tests with the ray's shared reciprocals where they are exact */
     pm.half_w = P.half_w; pm.half_h = P.half_h; pm.max_segments = P.max_segments;
     pm.rng.seed0 = P.seed0; pm.rng.seed1 = P.seed1;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -1003,6 +1006,12 @@ rt_finish_kernel(const FinishParams P)
         dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
         pm.phase = rt::PH_DEAD;
     };
+#if defined(RT_FINISH_CLOCKS)
+    unsigned long long ftick[4] = {0, 0, 0, 0}, fcount[4] = {0, 0, 0, 0}, flanes[4] = {0, 0, 0, 0}, ftick_prev = __builtin_readcyclecounter();
+#define RT_FTICK(i, lanes) { const unsigned long long now = __builtin_readcyclecounter(); ftick[i] += now - ftick_prev; ftick_prev = now; fcount[i]++; flanes[i] += (unsigned long long)(lanes); }
+#else
+#define RT_FTICK(i, lanes)
+#endif
     /* The in-wave scheduler of PathMachine::run with one change: an open leaf is tested by the whole wave at once
      * (this kernel's waves run with few paths, and its duration is the longest path's chain of steps: a leaf of
      * sixteen triangles is one step of that chain instead of sixteen). */
@@ -1034,6 +1043,7 @@ rt_finish_kernel(const FinishParams P)
         const int n_tri = __popcll(__ballot(pm.wants_tri()));
         const int n_pop = __popcll(__ballot(pm.wants_pop()));
         if (!(n_shade | n_tri | n_pop)) break;
+        RT_FTICK(0, n_shade + n_tri + n_pop)
         /* a full wave runs the kind of step most lanes want (a shade step is long, so it should run fuller);
          * a wave with few paths left runs every kind in turn, so that each path moves on in every iteration
          * (pop, then the leaf it opened, then the shading of the answer) */
@@ -1044,7 +1054,8 @@ rt_finish_kernel(const FinishParams P)
         const bool vote_pop = !vote_shade && s_pop >= s_tri;
         if (sparse ? n_pop > 0 : vote_pop) {
             if (STATS) { if (lane == 0) cn.pop_steps++; if (pm.wants_pop()) cn.pop_lanes++; }
-            if (pm.wants_pop()) pm.after_tree(rt::query_pop_step<STATS>(P.S, pm.h, pm.tv, stk, cn));
+            if (pm.wants_pop()) pm.after_tree(rt::query_pop_step<STATS, true>(P.S, pm.h, pm.tv, stk, cn));
+            RT_FTICK(1, n_pop)
         }
         if (sparse || !(vote_shade || vote_pop)) {
             const bool want_tri = pm.wants_tri();
@@ -1054,13 +1065,30 @@ rt_finish_kernel(const FinishParams P)
                 const bool accepted = wave_leaf_pass<STATS>(P.S, want_tri, tri_mask, any_hit, pm.h, pm.tv, lane, lanes_below,
                                                             leaf_best, leaf_marks, leaf_bary, cn);
                 if (want_tri && accepted && any_hit) pm.after_tree(rt::STEP_QUERY_DONE);
+                RT_FTICK(2, __popcll(tri_mask))
             }
         }
         if (sparse ? __ballot(pm.wants_shade()) != 0ull : vote_shade) {
             if (STATS) { if (lane == 0) cn.shade_steps++; if (pm.wants_shade()) cn.shade_lanes++; }
+#if defined(RT_FINISH_CLOCKS)
+            const int shade_lanes_now = __popcll(__ballot(pm.wants_shade()));
+#endif
             pm.shade_step(on_end);
+            RT_FTICK(3, shade_lanes_now)
         }
     }
+#if defined(RT_FINISH_CLOCKS)
+    if (lane == 0) {
+        const unsigned long long all = ftick[0] + ftick[1] + ftick[2] + ftick[3];
+        if (atomicMax(&rt_finish_clock_max, all) < all)
+            printf("finish wave %u.%u: clocks %llu; iterations %llu (%.1f paths each); refill+ballots %llu; pop steps %llu: %llu clocks, %.1f lanes; "
+                   "leaf passes %llu: %llu clocks, %.1f lanes; shade steps %llu: %llu clocks, %.1f lanes\n",
+                   blockIdx.x, threadIdx.x >> 6, all, fcount[0], (double)flanes[0] / (double)(fcount[0] ? fcount[0] : 1), ftick[0],
+                   fcount[1], ftick[1], (double)flanes[1] / (double)(fcount[1] ? fcount[1] : 1),
+                   fcount[2], ftick[2], (double)flanes[2] / (double)(fcount[2] ? fcount[2] : 1),
+                   fcount[3], ftick[3], (double)flanes[3] / (double)(fcount[3] ? fcount[3] : 1));
+    }
+#endif
     flush_counters<STATS>(cn, P.stats);
 }
 

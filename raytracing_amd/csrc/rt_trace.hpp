@@ -828,7 +828,7 @@ enum : int { PH_SHADE = 0, PH_SCAN = 1, PH_TREE = 2, PH_DEAD = 3, PH_PARK = 4 };
 
 /* SPECULAR = false compiles the mirror and glass branches out: for scenes without such materials
  * (the host checks), whose kernels then carry neither their code nor their registers. */
-template <class Rng, bool STATS, bool SPECULAR = true>
+template <class Rng, bool STATS, bool SPECULAR = true, bool CACHE = false>
 struct PathMachine {
     const rt_dev_scene &S;
     Stack stk;
@@ -1058,7 +1058,7 @@ struct PathMachine {
             }
         }
         if (phase == PH_SCAN)
-            phase = query_scan<STATS>(S, o, d, h, tv, stk, cn) ? PH_TREE : PH_SHADE;
+            phase = query_scan<STATS, CACHE>(S, o, d, h, tv, stk, cn) ? PH_TREE : PH_SHADE;
     }
 
     /* ---- hand-over between kernels (counter generator only) ------------------- */
@@ -1202,7 +1202,7 @@ struct PathMachine {
                 shade_step(on_end);
             } else if (s_pop >= s_tri) {
                 if (STATS) { if ((threadIdx.x & 63) == 0) cn.pop_steps++; if (wants_pop()) cn.pop_lanes++; }
-                if (wants_pop()) after_tree(query_pop_step<STATS>(S, h, tv, stk, cn));
+                if (wants_pop()) after_tree(query_pop_step<STATS, CACHE>(S, h, tv, stk, cn));
             } else {
                 if (STATS) { if ((threadIdx.x & 63) == 0) cn.tri_steps++; if (wants_tri()) cn.tri_lanes++; }
                 if (wants_tri()) after_tree(query_tri_step<STATS>(S, ray == RAY_SHADOW, h, tv, cn));
