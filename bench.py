@@ -18,7 +18,7 @@ rounds of a frame are decided on the device, nothing is read back), so the host 
 --frames-in-flight calls under way (default 3), call j ordered on its own stream and using the
 handle's work-memory lane j mod F (options.lane): the latency-bound end of one frame runs beside
 the start of the next and, with N > 1, the all-gather overlaps rendering.  With N > 1 a call
-renders this rank's share of --frames-per-call consecutive frames (default min(N, 4); launches as
+renders this rank's share of --frames-per-call consecutive frames (default N, at most 8; launches as
 large as a whole frame's, one gather for all of them).  Every timed frame is complete (rendered,
 gathered, assembled) inside the timed region; ms_per_step is elapsed / K.  `ms_per_frame_single`
 is one frame alone (one call, synchronised), `scene_create_ms` the flatten + upload of the scene.
@@ -179,7 +179,7 @@ def main():
                     help="run the multi-process path (process group, packed bands, all-gather, assembly, reductions) even "
                          "with one rank: a functional check of the RCCL calls on a one-GPU machine")
     ap.add_argument("--frames-per-call", type=int, default=0,
-                    help="frames whose shares one render call produces (0 = 1 on one GPU, min(N, 4) when N GPUs share a frame)")
+                    help="frames whose shares one render call produces (0 = 1 on one GPU, min(N, 8) when N GPUs share a frame)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="render calls under way at once, each ordered on its own stream and using its own work-memory "
                          "lane of the one scene handle (0 = 3)")
@@ -227,7 +227,7 @@ def main():
     if args.frames_per_call > 0:
         per_call = args.frames_per_call
     else:
-        per_call = 1 if (not shared or by_samples) else min(world, 4)
+        per_call = 1 if (not shared or by_samples) else min(world, 8)
     if by_samples:
         per_call = 1
 
