@@ -528,6 +528,9 @@ struct TreeParams {
                                        * (the owners' reads of their records then fall on different LDS banks) */
 #define RT_STAGE_WORDS_PER_WAVE (RT_TREE_STAGE ? 4u * RT_STAGE_LOAD_WORDS : 0u)
 #define RT_TREE_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * (RT_LEAF_WORDS_PER_WAVE + RT_STAGE_WORDS_PER_WAVE) * 4u + (size_t)RT_TREE_TOP * 64u)   /* bytes per workgroup for the leaf passes, the staged node records and the tree tops */
+#ifndef RT_FINISH_REFILL
+#define RT_FINISH_REFILL 16       /* finish kernel: free lanes take new records once this many are free */
+#endif
 #ifndef RT_FINISH_SPARSE
 #define RT_FINISH_SPARSE 12       /* finish kernel: a wave with at most this many paths runs every kind of step in each iteration */
 #endif
@@ -1019,7 +1022,7 @@ rt_finish_kernel(const FinishParams P)
         /* free lanes take the next records, a quarter wave at a time */
         while (!input_done) {
             const unsigned long long need = __ballot(pm.phase == rt::PH_DEAD);
-            if (__popcll(need) < 16) break;
+            if (__popcll(need) < RT_FINISH_REFILL) break;
             if (in_cur >= in_end) {
                 uint32_t v = 0;
                 if (lane == 0) v = atomicAdd(&q->in_next, 64u);
