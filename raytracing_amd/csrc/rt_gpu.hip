@@ -1932,12 +1932,12 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
 
     const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
     const uint32_t resolve_grid = (uint32_t)((units * 64 + RT_BLOCK - 1) / RT_BLOCK);
-    /* parked records at or below which one launch finishes the paths: 1/64 of the batch's paths, within
-     * [65536, 1048576] (the finishing launch runs few lanes per wave, so a small batch must not leave it much;
-     * measured on three scenes at 1024x1024x64: a frame is shortest with about a million) */
-    uint64_t finish_paths = batch_spp * items_per_sample / 64;
-    if (finish_paths < 65536) finish_paths = 65536;
-    if (finish_paths > 1048576) finish_paths = 1048576;
+    /* parked records at or below which one launch finishes the paths.  Measured on three scenes: a frame of
+     * 1024x1024x64 (67 M paths) is shortest when the rounds stop at about a million records (the survivors of
+     * several rounds are long paths); a batch of half that or less when they stop at two million, which for an
+     * eighth of the frame is right after the first launch (a round's two launches cost as much for two million
+     * records as the finishing launch saves by getting fewer) */
+    const uint64_t finish_paths = batch_spp * items_per_sample <= (1ull << 25) ? (2u << 20) : (1u << 20);
     const uint32_t finish_below = K.finish_below >= 0 ? (uint32_t)K.finish_below : (uint32_t)finish_paths;
     /* a wave that has no input left and fewer paths than this hands them to the next round; needs the
      * finishing launch to end the batch (without it the rounds run to the last path themselves) */
