@@ -528,6 +528,9 @@ struct TreeParams {
                                        * (the owners' reads of their records then fall on different LDS banks) */
 #define RT_STAGE_WORDS_PER_WAVE (RT_TREE_STAGE ? 4u * RT_STAGE_LOAD_WORDS : 0u)
 #define RT_TREE_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * (RT_LEAF_WORDS_PER_WAVE + RT_STAGE_WORDS_PER_WAVE) * 4u + (size_t)RT_TREE_TOP * 64u)   /* bytes per workgroup for the leaf passes, the staged node records and the tree tops */
+#ifndef RT_FINISH_SHADE_WEIGHT
+#define RT_FINISH_SHADE_WEIGHT 8      /* finish kernel: weight (in 1/16ths) of a lane that wants a shade step in the vote for the kind of step to run (a shade step is long: it should run fuller; measured 2 ... 16) */
+#endif
 #ifndef RT_FINISH_REFILL
 #define RT_FINISH_REFILL 16       /* finish kernel: free lanes take new records once this many are free */
 #endif
@@ -1051,7 +1054,7 @@ rt_finish_kernel(const FinishParams P)
          * a wave with few paths left runs every kind in turn, so that each path moves on in every iteration
          * (pop, then the leaf it opened, then the shading of the answer) */
         const bool sparse = n_shade + n_tri + n_pop <= RT_FINISH_SPARSE;
-        const int s_shade = n_shade * RT_SHADE_WEIGHT;           /* weights in 1/16ths */
+        const int s_shade = n_shade * RT_FINISH_SHADE_WEIGHT;    /* weights in 1/16ths */
         const int s_tri = n_tri * 16, s_pop = n_pop * 16;
         const bool vote_shade = s_shade >= s_tri && s_shade >= s_pop;
         const bool vote_pop = !vote_shade && s_pop >= s_tri;
