@@ -167,7 +167,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *scene, float *device_pixels, uint3
  * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
  * counterpart in the reference.  The call makes no hipMalloc / hipFree / event creation and no
  * read-back: the kernels' work memory (queue counters, per-sample values, the list of paths in
- * transit) is a 15 MB array that is part of the library's code object, one copy per GPU, held until
+ * transit) is a 13 MB array that is part of the library's code object, one copy per GPU, held until
  * the process ends.  Limit: (8x8 pixel blocks of the region) x 64 x spp <= 65536 paths, e.g. a 64x64
  * tile (the reference's tile size, src/main.c:794-824) at 16 samples per pixel; larger calls fail
  * with RT_GPU_ERR_ARGUMENT.  options.frames must be 0 or 1; the other options (sample_offset,

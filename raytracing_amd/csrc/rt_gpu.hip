@@ -70,7 +70,7 @@ __device__ __forceinline__ void flush_counters(const rt::Counters &cn, uint64_t 
  *       A lane carries a path through events (draw -> ray -> lights, spheres,
  *       planes, instance root boxes -> bookkeeping) until the path ends (its
  *       value goes to the sample scratch) or its ray enters an instance's root
- *       box; then the lane writes the path as a 192-byte record to the parked
+ *       box; then the lane writes the path as a 160-byte record to the parked
  *       list and takes the next path: it never waits for a tree walk.
  *   rt_tree_kernel    walks the trees for the parked rays only (6 % of the
  *       rays of the benchmark frame, ~40 node/triangle steps each): small
@@ -243,10 +243,14 @@ rt_shade_kernel(const ShadeParams P)
         const uint32_t rank = (uint32_t)__popcll(empty & lanes_below);
         const bool mine = ((empty >> lane) & 1ull) && rank < n;
         if (mine) {
-            const uint32_t *src = P.in_list + (size_t)(in_cur + rank) * RT_RECORD_WORDS;
+            const uint32_t *ray_words = rt::ray_part(P.in_list, in_cur + rank);
+            const uint32_t *path_words = rt::path_part(P.in_list, P.out_capacity, in_cur + rank);
 #pragma unroll
-            for (uint32_t qd = 0; qd < 10u; qd++)
-                __builtin_amdgcn_global_load_lds(src + 4u * qd, stage + 4u * RT_SLOTS * qd, 16, 0, 0);
+            for (uint32_t qd = 0; qd < 4u; qd++)
+                __builtin_amdgcn_global_load_lds(ray_words + 4u * qd, stage + 4u * RT_SLOTS * qd, 16, 0, 0);
+#pragma unroll
+            for (uint32_t qd = 4; qd < 10u; qd++)
+                __builtin_amdgcn_global_load_lds(path_words + 4u * (qd - 4u), stage + 4u * RT_SLOTS * qd, 16, 0, 0);
         }
         flight |= __ballot(mine);
         in_cur += n;
@@ -287,7 +291,7 @@ rt_shade_kernel(const ShadeParams P)
         if (want) {
             uint32_t slot = rank < room ? out_cur + rank : next_base + (rank - room);
             if (slot < P.out_capacity) {
-                m.store_record(P.out_list + (size_t)slot * RT_RECORD_WORDS, sidx, ready_flag);
+                m.store_record(rt::ray_part(P.out_list, slot), rt::path_part(P.out_list, P.out_capacity, slot), sidx, ready_flag);
             } else {                                      /* cannot happen: the host sizes the lists for every path of the launch */
                 atomicAdd(&P.q->overflow, 1u);
             }
@@ -481,7 +485,7 @@ rt_shade_kernel(const ShadeParams P)
     }
     /* unused tail of the last reserved chunk: mark the slots empty */
     for (uint32_t slot = out_cur + lane; slot < out_end && slot < P.out_capacity; slot += 64)
-        P.out_list[(size_t)slot * RT_RECORD_WORDS] = 0u;
+        *rt::ray_part(P.out_list, slot) = 0u;
     if (lane == 0 && parked_here) atomicAdd(&P.q->parked, parked_here);
     flush_counters<STATS>(cn, P.stats);
 }
@@ -772,7 +776,7 @@ rt_tree_kernel(const TreeParams P)
 #define RT_TICK(i)
 #endif
     auto finish = [&]() {                                /* answer the query: write the hit back */
-        uint4 *q = reinterpret_cast<uint4 *>(P.list + (size_t)slot * RT_RECORD_WORDS);
+        uint4 *q = reinterpret_cast<uint4 *>(rt::ray_part(P.list, slot));
         q[2] = make_uint4(__float_as_uint(h.t), (uint32_t)h.type, h.id, h.inst);
         q[3] = make_uint4(__float_as_uint(h.beta), __float_as_uint(h.gamma), (uint32_t)h.material, w15);
         busy = false;
@@ -795,7 +799,7 @@ rt_tree_kernel(const TreeParams P)
             const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
             const uint32_t idx = in_cur + rank;
             if (!busy && idx < in_end) {
-                const uint4 *q = reinterpret_cast<const uint4 *>(P.list + (size_t)idx * RT_RECORD_WORDS);
+                const uint4 *q = reinterpret_cast<const uint4 *>(rt::ray_part(P.list, idx));
                 const uint4 a = q[0], b = q[1], c = q[2], e = q[3];
                 if ((a.x & 0x81u) == 1u) {               /* a record, and its query is not complete */
                     slot = idx;
@@ -1035,9 +1039,9 @@ rt_finish_kernel(const FinishParams P)
             }
             const uint32_t idx = in_cur + (uint32_t)__popcll(need & lanes_below);
             if (pm.phase == rt::PH_DEAD && idx < in_end &&
-                pm.load_record(list + (size_t)idx * RT_RECORD_WORDS, sample_index)) {
-                if (!(list[(size_t)idx * RT_RECORD_WORDS] & 0x80u)) {   /* the query still has a tree to walk */
-                    pm.tv.inst = (int)(list[(size_t)idx * RT_RECORD_WORDS + 15] & 0xFFFFu);   /* instance the ray was parked for */
+                pm.load_record(rt::ray_part(list, idx), rt::path_part(list, P.capacity, idx), sample_index)) {
+                if (!(rt::ray_part(list, idx)[0] & 0x80u)) {   /* the query still has a tree to walk */
+                    pm.tv.inst = (int)(rt::ray_part(list, idx)[15] & 0xFFFFu);   /* instance the ray was parked for */
                     pm.phase = rt::PH_SCAN;
                     if (STATS) cn.root_tests--;          /* counted when the ray was parked */
                 }
@@ -1262,7 +1266,7 @@ rt_hit_pack_kernel(const HitPackParams P)
         rt::Hit h;
         int park = -1;
         if (!rt::query_begin<true>(P.S, o, d, P.max_distance, false, h, cn)) park = rt::query_probe<true>(P.S, o, d, h, 0, cn);
-        uint4 *q = reinterpret_cast<uint4 *>(P.list + (size_t)i * RT_RECORD_WORDS);
+        uint4 *q = reinterpret_cast<uint4 *>(rt::ray_part(P.list, i));
         const uint32_t flags = (park >= 0 ? 1u : 0u) | ((uint32_t)rt::RAY_SEGMENT << 3) | (h.entered ? 0x40u : 0u);
         q[0] = make_uint4(flags, 0u, __float_as_uint(o.x), __float_as_uint(o.y));
         q[1] = make_uint4(__float_as_uint(o.z), __float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z));
@@ -1278,7 +1282,7 @@ rt_hit_unpack_kernel(const HitPackParams P, uint8_t *results)
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i < P.count) {
-        const uint4 *q = reinterpret_cast<const uint4 *>(P.list + (size_t)i * RT_RECORD_WORDS);
+        const uint4 *q = reinterpret_cast<const uint4 *>(rt::ray_part(P.list, i));
         const uint4 a = q[0], b = q[1], c = q[2], e = q[3];
         const rt::f3 o = rt::mk(__uint_as_float(a.z), __uint_as_float(a.w), __uint_as_float(b.x));
         const rt::f3 d = rt::mk(__uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
@@ -1342,7 +1346,7 @@ static int fail(int code, const std::string &what)
 
 /* ---- work memory of rt_gpu_render_region_static: one array per GPU, part of the code object ----
  * Layout (byte offsets): the two queue-counter records (256 each), the per-sample values
- * (12 bytes per path), then one parked list (192 bytes per slot).  `rt_static_scratch` is only a
+ * (12 bytes per path), then one parked list (160 bytes per slot).  `rt_static_scratch` is only a
  * name on the host: the array's address on a device comes from hipGetSymbolAddress, once per device
  * (static_scratch_of), and that pointer is what kernels and memsets get. */
 #define RT_STATIC_MAX_PATHS 65536u                       /* (8x8 pixel blocks of the region) x 64 x samples per pixel */
@@ -1835,7 +1839,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
 
     /* The call's samples are rendered in batches (whole samples per pixel of the region; whole frames when
      * the call makes several).  A batch needs 12 bytes per path for the sample values and two lists of
-     * 192-byte records for the paths in transit between launches.  Lists that hold every path of the batch
+     * 160-byte records for the paths in transit between launches.  Lists that hold every path of the batch
      * (+ one partly used chunk per wave) cannot fill up; where the budgets or the device do not allow
      * that, the lists get what is allowed and the batch's paths start in several passes: the launch that
      * starts paths stops taking portions of new work when its list is nearly full, the rounds carry those

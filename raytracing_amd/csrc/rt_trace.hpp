@@ -824,7 +824,16 @@ enum : int { PH_SHADE = 0, PH_SCAN = 1, PH_TREE = 2, PH_DEAD = 3, PH_PARK = 4 };
  * then 16..18 throughput, 19..21 radiance, 22..24 normal, 25..27 albedo, 28..30 direct,
  * 31 lights reached, 32 reached here, 33 shadow length^2, 34 shadow cosine, 35..38 generator,
  * 39 index of the sample's slot in the sample scratch. */
-#define RT_RECORD_WORDS 48
+#define RT_RAY_WORDS 16        /* the part of a record the tree kernel reads and answers (words 0..15): one aligned 64-byte piece */
+#define RT_PATH_WORDS 24       /* the rest of the path (words 16..39) */
+#define RT_RECORD_WORDS (RT_RAY_WORDS + RT_PATH_WORDS)
+/* A list of `capacity` records keeps the ray parts one after the other, then the path parts: the tree
+ * kernel's 64 bytes per record are whole memory sectors of their own, and the shade kernels move 160 bytes
+ * per record in two dense streams. */
+__device__ __forceinline__ uint32_t *ray_part(uint32_t *list, size_t i) { return list + i * RT_RAY_WORDS; }
+__device__ __forceinline__ const uint32_t *ray_part(const uint32_t *list, size_t i) { return list + i * RT_RAY_WORDS; }
+__device__ __forceinline__ uint32_t *path_part(uint32_t *list, size_t capacity, size_t i) { return list + capacity * RT_RAY_WORDS + i * RT_PATH_WORDS; }
+__device__ __forceinline__ const uint32_t *path_part(const uint32_t *list, size_t capacity, size_t i) { return list + capacity * RT_RAY_WORDS + i * RT_PATH_WORDS; }
 
 /* SPECULAR = false compiles the mirror and glass branches out: for scenes without such materials
  * (the host checks), whose kernels then carry neither their code nor their registers. */
@@ -1064,9 +1073,10 @@ struct PathMachine {
     /* ---- hand-over between kernels (counter generator only) ------------------- */
     int park_inst;                /* PH_PARK: instance whose tree the ray has to walk first */
 
-    __device__ __forceinline__ void store_record(uint32_t *rec, uint32_t sample_index, bool ready = false) const
+    __device__ __forceinline__ void store_record(uint32_t *ray_words, uint32_t *path_words, uint32_t sample_index, bool ready = false) const
     {
-        uint4 *q = reinterpret_cast<uint4 *>(rec);
+        uint4 *q = reinterpret_cast<uint4 *>(ray_words);
+        uint4 *r = reinterpret_cast<uint4 *>(path_words);
         const uint32_t flags = 1u | ((uint32_t)ev << 1) | ((uint32_t)ray << 3) | ((uint32_t)inside_glass << 5) |
                                ((uint32_t)rng.fresh << 6) | ((uint32_t)ready << 7) | ((uint32_t)seg << 8);
         q[0] = make_uint4(flags, x | (y << 16), __float_as_uint(o.x), __float_as_uint(o.y));
@@ -1074,33 +1084,43 @@ struct PathMachine {
         q[2] = make_uint4(__float_as_uint(h.t), (uint32_t)h.type, h.id, h.inst);
         q[3] = make_uint4(__float_as_uint(h.beta), __float_as_uint(h.gamma), (uint32_t)h.material,
                           ((uint32_t)park_inst & 0xFFFFu) | ((uint32_t)li << 16));   /* park_inst is -1 or unset when the query is complete */
-        q[4] = make_uint4(__float_as_uint(throughput.x), __float_as_uint(throughput.y), __float_as_uint(throughput.z),
+        r[0] = make_uint4(__float_as_uint(throughput.x), __float_as_uint(throughput.y), __float_as_uint(throughput.z),
                           __float_as_uint(radiance.x));
-        q[5] = make_uint4(__float_as_uint(radiance.y), __float_as_uint(radiance.z), __float_as_uint(n.x),
+        r[1] = make_uint4(__float_as_uint(radiance.y), __float_as_uint(radiance.z), __float_as_uint(n.x),
                           __float_as_uint(n.y));
-        q[6] = make_uint4(__float_as_uint(n.z), __float_as_uint(albedo.x), __float_as_uint(albedo.y),
+        r[2] = make_uint4(__float_as_uint(n.z), __float_as_uint(albedo.x), __float_as_uint(albedo.y),
                           __float_as_uint(albedo.z));
-        q[7] = make_uint4(__float_as_uint(direct.x), __float_as_uint(direct.y), __float_as_uint(direct.z),
+        r[3] = make_uint4(__float_as_uint(direct.x), __float_as_uint(direct.y), __float_as_uint(direct.z),
                           __float_as_uint(lights_reached));
-        q[8] = make_uint4(__float_as_uint(reached_here), __float_as_uint(shadow_len2), __float_as_uint(shadow_cos),
+        r[4] = make_uint4(__float_as_uint(reached_here), __float_as_uint(shadow_len2), __float_as_uint(shadow_cos),
                           rng.k0);
-        q[9] = make_uint4(rng.k1, rng.c0, rng.c1, sample_index);
+        r[5] = make_uint4(rng.k1, rng.c0, rng.c1, sample_index);
     }
 
     /* false = the slot holds no path */
-    __device__ __forceinline__ bool load_record(const uint32_t *rec, uint32_t &sample_index)
+    __device__ __forceinline__ bool load_record(const uint32_t *ray_words, const uint32_t *path_words, uint32_t &sample_index)
     {
-        return load_record(reinterpret_cast<const uint4 *>(rec), 1u, sample_index);
+        const uint4 *q = reinterpret_cast<const uint4 *>(ray_words);
+        const uint4 *r = reinterpret_cast<const uint4 *>(path_words);
+        const uint4 a = q[0];
+        if (!(a.x & 1u)) return false;
+        unpack(a, q[1], q[2], q[3], r[0], r[1], r[2], r[3], r[4], r[5], sample_index);
+        return true;
     }
 
-    /* the record's ten 16-byte quads are `stride` quads apart (1: a record in memory; more: a batch
-     * of records staged quad by quad in LDS) */
+    /* the record's ten 16-byte quads `stride` quads apart: a batch of records staged quad by quad in LDS */
     __device__ __forceinline__ bool load_record(const uint4 *q, uint32_t stride, uint32_t &sample_index)
     {
         const uint4 a = q[0];
         if (!(a.x & 1u)) return false;
-        const uint4 b = q[stride], c = q[2 * stride], e = q[3 * stride], f = q[4 * stride], g = q[5 * stride],
-                    i = q[6 * stride], j = q[7 * stride], k = q[8 * stride], l = q[9 * stride];
+        unpack(a, q[stride], q[2 * stride], q[3 * stride], q[4 * stride], q[5 * stride],
+               q[6 * stride], q[7 * stride], q[8 * stride], q[9 * stride], sample_index);
+        return true;
+    }
+
+    __device__ __forceinline__ void unpack(const uint4 a, const uint4 b, const uint4 c, const uint4 e, const uint4 f, const uint4 g,
+                                           const uint4 i, const uint4 j, const uint4 k, const uint4 l, uint32_t &sample_index)
+    {
         ev = (int)((a.x >> 1) & 3u); ray = (int)((a.x >> 3) & 3u); inside_glass = ((a.x >> 5) & 1u) != 0;
         rng.fresh = ((a.x >> 6) & 1u) != 0; seg = (int)(a.x >> 8);
         x = a.y & 0xFFFFu; y = a.y >> 16;
@@ -1119,7 +1139,6 @@ struct PathMachine {
         rng.k0 = k.w; rng.k1 = l.x; rng.c0 = l.y; rng.c1 = l.z;
         sample_index = l.w;
         phase = PH_SHADE;
-        return true;
     }
 
     /* shade step of the shade kernel: as shade_step, but a ray that enters an
