@@ -815,8 +815,8 @@ enum : int { EV_CAMERA = 0, EV_NEE = 1, EV_BOUNCE = 2, EV_TRACE_ONLY = 3 };
 enum : int { RAY_NONE = 0, RAY_SEGMENT = 1, RAY_SHADOW = 2 };
 enum : int { PH_SHADE = 0, PH_SCAN = 1, PH_TREE = 2, PH_DEAD = 3, PH_PARK = 4 };
 
-/* A path in transit between the shade kernel and the tree kernel: 48 words.
- * Words 0..15 (one 64-byte line) are all the tree kernel reads and writes:
+/* A path in transit between the shade kernel and the tree kernel: 40 words.
+ * Words 0..15 (the ray part) are all the tree kernel reads and writes:
  *   0 flags: valid | ev<<1 | ray<<3 | inside<<5 | fresh<<6 | ready<<7 | seg<<8      1 x | y<<16
  *     (ready: the query is complete, the record only waits to be carried on: no tree to walk)
  *   2..4 origin   5..7 direction   8 t  9 type  10 id  11 inst  12 beta  13 gamma  14 material
