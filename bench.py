@@ -154,6 +154,80 @@ def load_counters(args, W, H, spp):
     return cj if cj.get("workload") == f"{args.scene} {W}x{H} {spp} spp" else None
 
 
+def instruction_mix(c, rays):
+    """Vector instructions of one kind of launch per ray of the frame, from the SQ_INSTS_VALU* counters: 64-lane issue
+    slots (wave instructions x 64), the slots on active lanes, and the slots by class (f32 add / multiply / fma come almost
+    entirely from the expansions of correctly rounded divisions and square roots and from the dot products; "other" is
+    what no class counter sees: moves, selects, compares, lane exchanges)."""
+    total = c["valu_wave_instructions"]
+    per_ray = lambda n: round(64.0 * n / max(1.0, rays), 1)
+    classes = {"f32_add": c.get("SQ_INSTS_VALU_ADD_F32", 0.0), "f32_mul": c.get("SQ_INSTS_VALU_MUL_F32", 0.0),
+               "f32_fma": c.get("SQ_INSTS_VALU_FMA_F32", 0.0),
+               "f64": c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_FMA_F64", 0.0),
+               "int32": c.get("SQ_INSTS_VALU_INT32", 0.0), "transcendental": c.get("SQ_INSTS_VALU_TRANS_F32", 0.0),
+               "convert": c.get("SQ_INSTS_VALU_CVT", 0.0)}
+    out = {k: per_ray(v) for k, v in classes.items()}
+    out["other_move_select_compare_exchange"] = per_ray(max(0.0, total - sum(classes.values())))
+    return {"valu_lane_slots_per_ray": per_ray(total),
+            "valu_lane_instructions_per_ray": round(total * (c.get("lanes_active") or 64.0) / max(1.0, rays), 1),
+            "valu_lane_slots_per_ray_by_class": out}
+
+
+def secondary_scene(name, W, H, spp, seed, max_segments):
+    """One more scene beside the headline, frames one at a time on a handle of its own: the scene of the largest
+    configuration (dog + cat meshes, four instances, mirror sphere), where the tree walk is most of the frame.  Returns the
+    entry for the JSON line: frame time, rays per second, device time per kind of launch and, when the counter passes of
+    this scene are committed (profiles/counters_<scene>.json), the same issue and memory fractions as the headline."""
+    import torch
+    from raytracing_amd import gpu, scenes
+    sh = scenes.CONFIGS[name]()
+    g = gpu.GpuScene(sh)
+    buf = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    o = gpu.Options(max_segments=max_segments)
+    times = []
+    for k in range(4):                                   # the first call allocates the lane's work memory
+        torch.cuda.synchronize()
+        if k == 1:
+            g.reset_stats()
+        t1 = time.perf_counter()
+        g.render_region_device(buf.data_ptr(), W, H, (0, 0, W, H), spp, seed, o)
+        torch.cuda.synchronize()
+        times.append(1e3 * (time.perf_counter() - t1))
+    st = g.stats()
+    rays = st["rays"] / 3.0
+    ms = sorted(times[1:])[1]
+    g.reset_stats()
+    g.render_region_device(buf.data_ptr(), W, H, (0, 0, W, H), spp, seed, gpu.Options(max_segments=max_segments, flags=gpu.FLAG_KERNEL_TIMES))
+    torch.cuda.synchronize()
+    by_kind = g.stats_by_kernel()
+    rounds = g.stats()["rounds"]
+    out = {"workload": f"{name} {W}x{H} {spp} spp, {max_segments}-segment paths (the scene of config 5: dog + cat meshes + mirrors)",
+           "ms_per_frame_single": round(ms, 3), "value": round(rays / (ms * 1e-3) / 1e6, 2), "unit": "Mrays/s",
+           "rays_per_frame": round(rays), "rays_per_sample": round(rays / (W * H * spp), 3),
+           "shade_launches_with_work": int(rounds),
+           "frame_checksum": float(buf.double().sum().item()),
+           "work_memory_bytes": int(g.info()["work_bytes"]),
+           "kernels": {k: {"ms_per_frame": round(by_kind[k]["kernel_ms"], 3)} for k in KINDS}}
+    path = os.path.join(ROOT, "profiles", f"counters_{name}.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            cj = json.load(f)
+        if cj.get("workload") == f"{name} {W}x{H} {spp} spp":
+            out["counters_source"] = cj["source"]
+            for k in KINDS:
+                c, e = cj["kinds"].get(k), out["kernels"][k]
+                if not c or e["ms_per_frame"] <= 0:
+                    continue
+                sec = e["ms_per_frame"] * 1e-3
+                hbm = 2 * c["fetch_bytes_raw"] + c["write_bytes"]
+                e.update({"valu_issue_frac": round(c["valu_wave_instructions"] / sec / 1e9 / VALU_ISSUE_PEAK_GINST, 4),
+                          "lanes_active_per_valu_instruction": c.get("lanes_active"),
+                          "hbm_GBs": round(hbm / sec / 1e9, 1), "hbm_frac": round(hbm / sec / 1e9 / HBM_PEAK_GBS, 4)})
+                e.update(instruction_mix(c, rays))
+    g.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -275,6 +349,8 @@ def main():
         """Enqueue the call (asynchronous) and, when several GPUs share the frames, the gather behind it."""
         nonlocal frame
         sl.count = count
+        sl.first_frame = first_frame
+        sl.frames_out = []
         if by_samples:
             with torch.cuda.stream(sl.stream):
                 sl.mine.zero_()                        # this rank's samples are added to zeros
@@ -282,6 +358,8 @@ def main():
         o.flags |= extra_flags
         o.sample_offset = first_frame * spp + first_sample
         o.frames = count
+        if shared and not by_samples:
+            o.frame_stride = sl.mine.shape[1] * W * 3      # frames lie one packed buffer apart (the rank with the most rows), whatever this rank owns
         o.lane = sl.index
         g.render_region_device(sl.mine.data_ptr(), W, H, (0, 0, W, H), my_spp, args.seed, o, sl.stream.cuda_stream)
         if shared:
@@ -300,7 +378,9 @@ def main():
                         frame = multi_gpu.combine_partial_sums(shares, world, spp)
                     else:
                         frame = multi_gpu.assemble(shares, world, H, W, band)
+                    sl.frames_out.append(frame)
         else:
+            sl.frames_out = [sl.mine[j] for j in range(sl.count)]
             frame = sl.mine[sl.count - 1]
 
     def run_frames(first_frame, count, extra_flags=0, depth=in_flight):
@@ -326,7 +406,15 @@ def main():
     run_frames(0, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    rays = float(g.stats()["rays"])
+    timed_stats = g.stats()
+    rays = float(timed_stats["rays"])
+    # the frames of the timed run that are still in the slots' buffers (the last calls in flight), by frame index:
+    # frame i is samples i*spp ... of seed --seed whatever N and the frames per call are, so the sums must agree
+    timed_checksums = {}
+    for sl in slots:
+        if getattr(sl, "first_frame", 10**9) < args.steps:
+            for j, f in enumerate(sl.frames_out):
+                timed_checksums[str(sl.first_frame + j)] = float(f.double().sum().item())
 
     # one frame alone: a call, then wait for it
     single = []
@@ -391,6 +479,14 @@ def main():
                        "the tree shape is observable); compare with ms_per_frame_single"}
         g2.close()
 
+    secondary = None
+    if not shared and not args.no_side_measurements and args.scene == "dog_room":
+        try:
+            secondary = secondary_scene("dogs_and_cat", W, H, spp, args.seed, args.max_segments)
+        except Exception as e:      # a side measurement: never lose the headline line over it
+            secondary = {"workload": "dogs_and_cat", "failed": str(e)}
+    model = {"dog_room": "dog.obj", "three_dogs": "dog.obj x3", "dogs_and_cat": "dog.obj + cat.obj"}.get(args.scene, args.scene)
+    metric_name = f"Mrays/s (all bounces), {model} {W}x{H} {spp} spp"
     if rank == 0:
         counters = load_counters(args, W, H, spp) if not shared else None
         resumed_launches = max(0.0, launches_with_work - 1)
@@ -404,6 +500,7 @@ def main():
                  "algorithmic_GBs": round(abytes_kind[i] / max(1e-9, kind_ms[i] * 1e-3) / 1e9, 1)}
             if counters and k in counters["kinds"]:
                 c = counters["kinds"][k]
+                e.update(instruction_mix(c, float(det["rays"])))
                 ginst = c["valu_wave_instructions"] / max(1e-9, kind_ms[i] * 1e-3) / 1e9
                 hbm = (2 * c["fetch_bytes_raw"] + c["write_bytes"])
                 e.update({"valu_wave_instructions_per_frame": int(c["valu_wave_instructions"]),
@@ -458,7 +555,7 @@ def main():
                                                  "sphere_tests", "plane_tests")},
         }
         out = {
-            "metric": "Mrays/s (all bounces), dog.obj 1024x1024 64 spp",
+            "metric": metric_name,
             "value": round(rays / elapsed / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -495,11 +592,16 @@ def main():
                 "frames_in_flight": in_flight * per_call,
                 "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                 "frame_checksum_seed0": checksum,
+                "frame_checksums_timed": timed_checksums,
+                "passes_per_batch": round(timed_stats["passes"] / max(1, timed_stats["launches"]), 2),
+                "work_memory_bytes": int(g.info()["work_bytes"]),
             },
             "roofline": roofline,
         }
         if sah:
             out["surface_area_tree"] = sah
+        if secondary:
+            out["secondary"] = secondary
         if not shared and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sh, W, H)

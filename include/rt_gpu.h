@@ -77,7 +77,9 @@ typedef struct rt_gpu_options {
                               * its own hip_stream, overlap on the GPU: two or three frames in flight from one host
                               * thread.  0 = the first lane */
     uint64_t frame_stride;   /* floats between the first pixels of consecutive frames; 0 = the size of one frame's
-                              * output (width*height*3, or this rank's packed bands) */
+                              * output: width*height*3, or with packed bands rt_gpu_multi_rows_per_rank(region height,
+                              * band_rows, band_count) rows of the region's width (the buffer of the rank with the most
+                              * rows: the same on every rank, as an all-gather of the ranks' buffers needs) */
 } rt_gpu_options;
 
 /* Work counters of the calls since the last rt_gpu_reset_stats.  A "ray" is
@@ -154,9 +156,10 @@ int rt_gpu_render_region(rt_gpu_scene *scene, rt_image3f *image, rt_rect2u regio
  * rounds a frame needs is decided on the device; launches with nothing to do
  * return at once) and reads nothing back.  The samples of a call are rendered in
  * batches that go round-robin over a few streams of the library's own
- * (RT_GPU_STREAMS, default 3; RT_GPU_BATCH_PATHS paths per batch, default 16 Mi), so
- * the latency-bound end of one batch overlaps the start of the next; the
- * picture does not depend on the batching.  Work that consumes the pixels goes
+ * (RT_GPU_STREAMS, default 3; RT_GPU_BATCH_PATHS paths per batch, default 80 Mi, then
+ * cut down to what RT_GPU_SCRATCH_MB, RT_GPU_PARKED_MB and the free device memory
+ * allow: a 1024 x 1024 x 64 spp frame is one batch), so the latency-bound end of one
+ * batch overlaps the start of the next; the picture does not depend on the batching.  Work that consumes the pixels goes
  * on `hip_stream` (or synchronises with it).  The buffer belongs to the caller
  * (e.g. a tensor that a collective will gather). */
 int rt_gpu_render_region_device(rt_gpu_scene *scene, float *device_pixels, uint32_t width, uint32_t height,

@@ -1297,6 +1297,13 @@ rt_hit_unpack_kernel(const HitPackParams P, uint8_t *results)
     flush_counters<true>(cn, P.stats);
 }
 
+/* zeroes `count` 32-bit words (the queue counters of the static work memory: as a kernel, so that inside a captured
+ * graph the clearing is a kernel node ordered like every other launch of the sequence) */
+__global__ void rt_clear_words_kernel(uint32_t *words, uint32_t count)
+{
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) words[i] = 0u;
+}
+
 __global__ void rt_normalize_kernel(float *p, size_t n, float factor)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1413,6 +1420,7 @@ struct rt_gpu_scene {
     QueueCounters *d_queue = nullptr; /* closest-hit probes */
     BatchLane lanes[RT_MAX_LANES];
     hipEvent_t ev_start = nullptr;
+    hipStream_t host_stream = nullptr;                        /* rt_gpu_render_region (host image) orders its render here */
     Knobs knobs;
     uint32_t shade_blocks = 0, resume_blocks = 0, tree_blocks = 0, finish_blocks = 0;   /* persistent grid sizes */
     bool specular = true;                                     /* some material is a mirror or glass */
@@ -1515,6 +1523,7 @@ void rt_gpu_scene_destroy(rt_gpu_scene *s)
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
+    if (s->host_stream) (void)hipStreamDestroy(s->host_stream);
     for (auto &t : s->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     for (auto e : s->spare_events) (void)hipEventDestroy(e);
     delete s;
@@ -1633,7 +1642,8 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
         }
         {   /* one stream, one record table and one event per batch lane; their work memory comes with the first render */
-            bool ok = hipEventCreateWithFlags(&s->ev_start, hipEventDisableTiming) == hipSuccess;
+            bool ok = hipEventCreateWithFlags(&s->ev_start, hipEventDisableTiming) == hipSuccess &&
+                      hipStreamCreateWithFlags(&s->host_stream, hipStreamNonBlocking) == hipSuccess;
             for (uint32_t i = 0; ok && i < s->knobs.lanes; i++) {
                 BatchLane &L = s->lanes[i];
                 ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess &&
@@ -1808,7 +1818,11 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     if ((uint64_t)spp * frames + (o ? o->sample_offset : 0) > 0xFFFFFFFFull) return fail(RT_GPU_ERR_ARGUMENT, "sample indices exceed 32 bits");
     const uint64_t frame_floats = (flags & RT_GPU_FLAG_COMPACT_BANDS) ? (uint64_t)own_rows * region.size.x * 3
                                                                       : (uint64_t)width * height * 3;
-    const uint64_t frame_stride = (o && o->frame_stride) ? o->frame_stride : frame_floats;
+    /* packed bands: the default distance between frames is the packed buffer of the rank with the most rows, the same
+     * for every rank (what an all-gather of the ranks' buffers needs), not this rank's own row count */
+    const uint64_t default_stride = (flags & RT_GPU_FLAG_COMPACT_BANDS) && o && o->band_rows
+        ? (uint64_t)rt_gpu_multi_rows_per_rank(region.size.y, o->band_rows, o->band_count) * region.size.x * 3 : frame_floats;
+    const uint64_t frame_stride = (o && o->frame_stride) ? o->frame_stride : default_stride;
     if (frames > 1 && frame_stride < frame_floats) return fail(RT_GPU_ERR_ARGUMENT, "frame_stride is smaller than a frame");
     const uint64_t total_spp = (uint64_t)spp * frames;
     if (o && o->lane >= K.lanes) return fail(RT_GPU_ERR_ARGUMENT, "options.lane must be below RT_GPU_STREAMS (" + std::to_string(K.lanes) + ")");
@@ -2114,7 +2128,8 @@ int rt_gpu_render_region_static(rt_gpu_scene *s, float *device_pixels, uint32_t 
     if (shade_grid > 32u) shade_grid = 32u;
     if (shade_grid > s->shade_blocks) shade_grid = s->shade_blocks;
 
-    RT_HIP(hipMemsetAsync(base, 0, 512, stream));
+    hipLaunchKernelGGL(rt_clear_words_kernel, dim3(1), dim3(128), 0, stream, reinterpret_cast<uint32_t *>(base), RT_STATIC_SAMPLES_AT / 4u);
+    RT_HIP(hipGetLastError());
     launch_shade(true, detailed, s->specular, shade_grid, stream, P);
     RT_HIP(hipGetLastError());
 
@@ -2180,9 +2195,11 @@ int rt_gpu_render_region(rt_gpu_scene *s, rt_image3f *image, rt_rect2u region, u
     const size_t pitch = (size_t)W * 3 * sizeof(float);
     if (o && (o->flags & RT_GPU_FLAG_ACCUMULATE))
         RT_HIP(hipMemcpy2D(d0, pitch, h0, pitch, row_bytes, region.size.y, hipMemcpyHostToDevice));
-    rc = rt_gpu_render_region_device(s, s->d_frame, W, H, region, spp, seed, o, nullptr);
+    /* ordered on a stream of the handle's own, and only that stream is waited for: a host that drives other handles or
+     * devices from other threads is not held up by their queues (as a device-wide wait would be) */
+    rc = rt_gpu_render_region_device(s, s->d_frame, W, H, region, spp, seed, o, s->host_stream);
     if (rc) return rc;
-    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipStreamSynchronize(s->host_stream));
     if (o && o->band_rows) {
         /* copy back only the rows of this rank's bands */
         const uint32_t band = o->band_rows;

@@ -17,6 +17,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -36,9 +37,11 @@ struct Rccl {
     int (*group_start)() = nullptr;
     int (*group_end)() = nullptr;
     const char *(*error_string)(int) = nullptr;
-    bool load()
+    std::mutex guard;
+    bool load()                      /* any thread, any number of times: the first call loads, the others find it loaded */
     {
-        if (lib) return true;
+        std::lock_guard<std::mutex> hold(guard);
+        if (lib) return comm_init_all && comm_destroy && all_gather && group_start && group_end;
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (lib) break;

@@ -37,6 +37,11 @@ def test_two_and_three_ranks_assemble_the_single_process_frame():
         assert many["n_gpus"] == world and many["steps"] == 3 and many["scaling"] == "strong"
         assert many["config"]["frame_checksum_seed0"] == one["config"]["frame_checksum_seed0"]
         assert many["config"]["rays_per_step"] == one["config"]["rays_per_step"]
+        # every frame of the timed run, those that were the second or third frame of a call included (200 rows over 3
+        # ranks is an uneven split: ranks own 72, 64 and 64 rows), equals the single process's frame of that index
+        assert many["config"]["frames_per_call"] == world
+        assert many["config"]["frame_checksums_timed"] == one["config"]["frame_checksums_timed"]
+        assert sorted(one["config"]["frame_checksums_timed"]) == ["0", "1", "2"]
         assert many["metric"] == one["metric"] and many["unit"] == "Mrays/s" and many["value"] > 0
 
 

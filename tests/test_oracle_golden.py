@@ -168,3 +168,20 @@ def test_fused_build_differs_only_statistically(golden):
         a, b = g[name + "_build"], g[name + "_strict"]
         assert not L.same_bits(a, b).all()
         assert abs(np.nanmean(a) - np.nanmean(b)) < 0.15 * np.nanmean(b)
+
+
+def test_literal_tolerance_shares_of_the_reference_against_itself(golden):
+    """How much of a frame two builds of the SAME reference source agree on within 1e-5 relative when
+    they consume the same random streams: build.sh flags (gcc fuses some multiply-adds) against the
+    same flags + -ffp-contract=off, 25 jobs per scene, 2 samples per pixel.  A last-bit difference
+    flips a grazing shadow ray (src/main.c:582-599 with :307) and the sample takes another path, so
+    the share of pixels inside the tolerance is small in every lit scene and no re-implementation
+    can be held to more; the device test of the same name measures the HIP path against the same
+    build-flag buffers."""
+    g = golden("region_kat")
+    for name, low, high in (("deux_spheres", 0.30, 0.50), ("sphere_room", 0.05, 0.20), ("dog_room", 0.05, 0.20),
+                            ("dogs_and_cat", 0.05, 0.20)):
+        build, strict = g[name + "_build"], g[name + "_strict"]
+        close = np.abs(strict - build) <= 1e-5 * np.abs(build)
+        share = float(close.all(axis=2).mean())
+        assert low < share < high, (name, share)
