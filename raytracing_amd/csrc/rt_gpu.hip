@@ -201,7 +201,6 @@ rt_shade_kernel(const ShadeParams P)
     rt::Stack stk; stk.base = nullptr; stk.stride = 0;                      /* this kernel walks no tree */
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
     const uint32_t lane = threadIdx.x & 63;
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
     rt::PathMachine<rt::CounterRng, STATS, SPECULAR> pm(P.S, stk, cn);
     pm.half_w = P.half_w; pm.half_h = P.half_h; pm.max_segments = P.max_segments;
@@ -240,7 +239,7 @@ rt_shade_kernel(const ShadeParams P)
         }
         const uint32_t room = (uint32_t)__popcll(empty);
         const uint32_t n = in_end - in_cur < room ? in_end - in_cur : room;
-        const uint32_t rank = (uint32_t)__popcll(empty & lanes_below);
+        const uint32_t rank = rt::bits_below_lane(empty);
         const bool mine = ((empty >> lane) & 1ull) && rank < n;
         if (mine) {
             const uint32_t *ray_words = rt::ray_part(P.in_list, in_cur + rank);
@@ -279,7 +278,7 @@ rt_shade_kernel(const ShadeParams P)
         const unsigned long long parking = __ballot(want);
         if (!parking) return;
         const uint32_t count = (uint32_t)__popcll(parking);
-        const uint32_t rank = (uint32_t)__popcll(parking & lanes_below);
+        const uint32_t rank = rt::bits_below_lane(parking);
         const uint32_t room = out_end - out_cur;
         uint32_t next_base = 0;
         if (count > room) {                              /* reserve the next chunk; the old one is filled to its end */
@@ -357,7 +356,7 @@ rt_shade_kernel(const ShadeParams P)
         park(to_park, cam, sidx);
         const unsigned long long pushing = __ballot(to_pool);
         if (to_pool) {
-            const uint32_t e = pool_n + (uint32_t)__popcll(pushing & lanes_below);
+            const uint32_t e = pool_n + rt::bits_below_lane(pushing);
             pool[e] = make_uint4(cam.x | (cam.y << 16), sidx, __float_as_uint(cam.d.x), __float_as_uint(cam.d.y));
             pool[RT_POOL + e] = make_uint4(__float_as_uint(cam.d.z), __float_as_uint(cam.h.t), (uint32_t)cam.h.type, cam.h.id);
             pool[2u * RT_POOL + e] = make_uint4((uint32_t)cam.h.material, cam.rng.k0, cam.rng.k1, 0u);
@@ -373,7 +372,7 @@ rt_shade_kernel(const ShadeParams P)
             if (want) {
                 while (pool_n < want && !input_done) camera_step();   /* always 64 new paths: the pool holds < 64 + 64 */
                 const uint32_t take = want < pool_n ? want : pool_n;
-                const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
+                const uint32_t rank = rt::bits_below_lane(need);
                 if (!has && rank < take) {
                     const uint32_t e = pool_n - 1u - rank;
                     const uint4 a = pool[e], b = pool[RT_POOL + e], c = pool[2u * RT_POOL + e];
@@ -433,11 +432,11 @@ rt_shade_kernel(const ShadeParams P)
                     const unsigned long long slots = __ballot(((ready >> lane) & 1ull) && slot_kind == best);
                     const unsigned long long need = __ballot(!has);
                     const uint32_t take = (uint32_t)a[best];
-                    const uint32_t srank = (uint32_t)__popcll(slots & lanes_below);
+                    const uint32_t srank = rt::bits_below_lane(slots);
                     const bool given = ((slots >> lane) & 1ull) && srank < take;
                     if (given) pick[srank] = lane;
                     ready &= ~__ballot(given);
-                    const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
+                    const uint32_t rank = rt::bits_below_lane(need);
                     if (!has && rank < take) {
                         const uint32_t j = pick[rank];
                         has = pm.load_record(reinterpret_cast<const uint4 *>(stage) + j, RT_SLOTS, sample_index);
@@ -492,20 +491,25 @@ rt_shade_kernel(const ShadeParams P)
 
 struct TreeParams {
     rt_dev_scene S;
-    uint32_t *list;                  /* parked records: word 0..15 read, 8..14 written back */
+    uint32_t *list;                  /* parked records: words 0..8 and 15 read, words 8..14 written when a triangle is accepted */
     uint32_t capacity;               /* slots of the list */
     uint32_t fixed_slots;            /* not 0: answer exactly this many slots (closest-hit probes); 0: what the round's record says */
     uint32_t finish_below;           /* the round's records are left to the finishing launch unless there are more than this */
     QueueCounters *q;                /* the record of the round that parked the list */
     uint64_t *stats;
+    uint32_t *spill;                 /* stack entries beyond the LDS levels: (stack_cap - stack_levels) x threads of the launch */
+    uint32_t stack_levels;           /* stack entries per ray kept in LDS */
+    uint64_t *depth_hist;            /* counting builds: rays by the deepest stack they needed (RT_DEPTH_BINS bins), or NULL */
 };
 
+#define RT_DEPTH_BINS 32u
 #ifndef RT_TREE_WAVES
-#define RT_TREE_WAVES 5               /* waves per SIMD the tree kernel is compiled for (0: compiler's choice); its LDS
-                                       * (stacks + leaf-pass slots, 30 KB per workgroup for a 26-level tree) allows 5 */
+#define RT_TREE_WAVES 6               /* waves per SIMD the tree kernel is compiled for (0: compiler's choice): 80 registers; with its
+                                       * short LDS stack the workgroup needs 13 KB of LDS, so registers are what limits it */
 #endif
-#ifndef RT_TREE_SPECULATE
-#define RT_TREE_SPECULATE 0           /* 1: request both children's records while the visited node's boxes are tested */
+#ifndef RT_TREE_STACK_LDS
+#define RT_TREE_STACK_LDS 8u          /* stack entries per ray the tree kernel keeps in LDS (deeper ones go to device memory);
+                                       * RT_GPU_TREE_STACK overrides it per scene handle */
 #endif
 #ifndef RT_TREE_LEAF_MIN
 #define RT_TREE_LEAF_MIN 16           /* rays waiting at a leaf that make a leaf pass worth running beside node steps */
@@ -519,19 +523,8 @@ struct TreeParams {
 #ifndef RT_LEAF_REDO
 #define RT_LEAF_REDO 0                /* the ray that accepted a triangle computes its barycentrics again (0: the pair that won leaves them in LDS) */
 #endif
-#ifndef RT_TREE_STAGE
-#define RT_TREE_STAGE 0               /* 1: node records come through LDS, each fetched by four neighbouring lanes (one 64-byte line per
-                                       * request) instead of four 16-byte requests of the lane that owns the ray (experiment: no gain
-                                       * at equal occupancy, and its 16 KB of LDS per workgroup cost two of five resident workgroups) */
-#endif
-#if RT_TREE_STAGE && (RT_TREE_TOP || RT_TREE_SPECULATE)
-#error "RT_TREE_STAGE replaces the RT_TREE_TOP and RT_TREE_SPECULATE experiments"
-#endif
 #define RT_LEAF_WORDS_PER_WAVE (128u + (RT_LEAF_REDO ? 0u : 128u) + (RT_LEAF_MARKS ? 32u : 0u))   /* LDS words per wave for the leaf passes: 64 keys (2 words), 1024 mark bits, 64 x (beta, gamma) */
-#define RT_STAGE_LOAD_WORDS 260u      /* one staged load of a wave: 64 lanes x 16 bytes, and 16 bytes of skew between the four loads
-                                       * (the owners' reads of their records then fall on different LDS banks) */
-#define RT_STAGE_WORDS_PER_WAVE (RT_TREE_STAGE ? 4u * RT_STAGE_LOAD_WORDS : 0u)
-#define RT_TREE_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * (RT_LEAF_WORDS_PER_WAVE + RT_STAGE_WORDS_PER_WAVE) * 4u + (size_t)RT_TREE_TOP * 64u)   /* bytes per workgroup for the leaf passes, the staged node records and the tree tops */
+#define RT_TREE_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * RT_LEAF_WORDS_PER_WAVE * 4u + (size_t)RT_TREE_TOP * 64u)   /* bytes per workgroup for the leaf passes and the tree tops */
 #ifndef RT_FINISH_SHADE_WEIGHT
 #define RT_FINISH_SHADE_WEIGHT 8      /* finish kernel: weight (in 1/16ths) of a lane that wants a shade step in the vote for the kind of step to run (a shade step is long: it should run fuller; measured 2 ... 16) */
 #endif
@@ -556,7 +549,7 @@ struct TreeParams {
 template <bool STATS>
 __device__ __forceinline__ bool wave_leaf_pass(const rt_dev_scene &S, const bool want_tri, const unsigned long long tri_mask,
                                                const bool any_hit, rt::Hit &h, rt::Trav &tv, const uint32_t lane,
-                                               const unsigned long long lanes_below, unsigned long long *leaf_best,
+                                               unsigned long long *leaf_best,
                                                uint32_t *leaf_marks, float *leaf_bary, rt::Counters &cn)
 {
     (void)leaf_marks; (void)leaf_bary;
@@ -578,8 +571,8 @@ __device__ __forceinline__ bool wave_leaf_pass(const rt_dev_scene &S, const bool
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     /* owners packed to the low lanes in lane order (= order of their first pairs): packed owner i is
      * the i-th ray with pairs */
-    const uint32_t dest = want_tri ? (uint32_t)__popcll(tri_mask & lanes_below)
-                                   : (uint32_t)n_tri + (uint32_t)__popcll(~tri_mask & lanes_below);
+    const uint32_t dest = want_tri ? rt::bits_below_lane(tri_mask)
+                                   : (uint32_t)n_tri + rt::bits_below_lane(~tri_mask);
     const uint32_t packed_lane = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest * 4u), (int)lane);
 #if RT_LEAF_MARKS
     /* which ray owns pair k: the rays mark their first pairs in a bit table (at most 64 x 16 pairs); the 64 bits
@@ -600,8 +593,9 @@ __device__ __forceinline__ bool wave_leaf_pass(const rt_dev_scene &S, const bool
         const uint32_t k = base + lane;
 #if RT_LEAF_MARKS
         const uint32_t starts_lo = leaf_marks[base >> 5], starts_hi = leaf_marks[(base >> 5) + 1u];   /* the same words for every lane */
-        const unsigned long long upto = lanes_below | (1ull << lane);
-        const uint32_t pos = owners_before + (uint32_t)__popc(starts_lo & (uint32_t)upto) + (uint32_t)__popc(starts_hi & (uint32_t)(upto >> 32)) - 1u;
+        const unsigned long long starts = ((unsigned long long)starts_hi << 32) | starts_lo;
+        /* owners whose first pair lies at or before this lane's pair: those below the lane, and its own bit */
+        const uint32_t pos = owners_before + rt::bits_below_lane(starts) + (uint32_t)((starts >> lane) & 1ull) - 1u;
         owners_before += (uint32_t)__popc(starts_lo) + (uint32_t)__popc(starts_hi);
 #else
         uint32_t pos = 0;                            /* last packed owner whose first pair is <= k */
@@ -693,6 +687,13 @@ __device__ __forceinline__ bool wave_leaf_pass(const rt_dev_scene &S, const bool
     return accepted;
 }
 
+/* Answers the parked queries of one round: every record whose query is not complete has its ray walked through
+ * the trees of the instances from the one it was parked for on (src/main.c:372-483).  A lane keeps only what the
+ * walk itself needs (slot, closest distance, ray in mesh space, stack pointer, the prefetched node record): origin
+ * and direction are read again from the record when the next instance's root box is due, and a triangle that is
+ * accepted goes to the record at once (distance, identity, barycentrics: words 8..14), so an unanswered record is
+ * simply left as it was.  Few registers and a short LDS stack are what let many waves share a SIMD here, and many
+ * waves are what hides the dependent fetches of a walk. */
 template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) RT_TREE_ATTR
 rt_tree_kernel(const TreeParams P)
@@ -705,34 +706,24 @@ rt_tree_kernel(const TreeParams P)
     }
     if (blockIdx.x >= (slots + 255u) / 256u) return;
     extern __shared__ uint32_t lds[];
-    rt::Stack stk; stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK;
+    rt::TreeStack stk;
+    stk.base = lds + threadIdx.x; stk.stride = RT_BLOCK; stk.levels = (int)P.stack_levels;
+    stk.spill = P.spill; stk.spill_stride = gridDim.x * RT_BLOCK; stk.thread = blockIdx.x * RT_BLOCK + threadIdx.x;
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
     const uint32_t lane = threadIdx.x & 63;
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
     /* after the stacks: per wave 64 keys (8 bytes) and 64 barycentric pairs for the leaf passes */
-    uint32_t *leaf_area = lds + (size_t)RT_BLOCK * P.S.stack_cap + (threadIdx.x >> 6) * RT_LEAF_WORDS_PER_WAVE;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *leaf_area = lds + (size_t)RT_BLOCK * P.stack_levels + wave * RT_LEAF_WORDS_PER_WAVE;
     unsigned long long *leaf_best = reinterpret_cast<unsigned long long *>(leaf_area);
     uint32_t *leaf_marks = leaf_area + 128;              /* 32 words (if RT_LEAF_MARKS) */
     float *leaf_bary = reinterpret_cast<float *>(leaf_area + 128 + (RT_LEAF_MARKS ? 32 : 0));   /* 128 words (unless RT_LEAF_REDO) */
     (void)leaf_bary; (void)leaf_marks;
-#if RT_TREE_STAGE
-    /* Node records through LDS.  A lane that fetched its own 64-byte record with four 16-byte loads made four
-     * requests for one line, and the 64 lanes of a wave 256 per node step: the address and tag pipeline of the
-     * vector memory unit, not arithmetic or latency, was what this kernel waited for (asking for every record
-     * twice made it 53 % slower).  Here the four lanes of a quad fetch the four quarters of ONE record in one
-     * load (a whole line per request: 64 requests per node step), written straight to LDS: load i of a step
-     * serves the rays of lanes 4j + i, and lane L finds its record at word i * 260 + 16 * j of the wave's area. */
-    uint32_t *node_stage = lds + (size_t)RT_BLOCK * P.S.stack_cap + (RT_BLOCK / 64) * RT_LEAF_WORDS_PER_WAVE +
-                           (threadIdx.x >> 6) * RT_STAGE_WORDS_PER_WAVE;
-    const rt::u32x4 *my_record = reinterpret_cast<const rt::u32x4 *>(node_stage + (lane & 3u) * RT_STAGE_LOAD_WORDS + (lane >> 2) * 16u);
-    const uint32_t *nodes_words = reinterpret_cast<const uint32_t *>(P.S.nodes) + (lane & 3u) * 4u;   /* this lane's quarter of a record */
-#endif
 
 #if RT_TREE_TOP
     /* The first records of a mesh's node range are the top levels of its tree (breadth-first order): every walk
      * passes through them.  Each workgroup keeps a copy in LDS, so those visits cost an LDS read instead of a
      * 64-byte line through the vector memory pipeline. */
-    uint32_t *tops = lds + (size_t)RT_BLOCK * P.S.stack_cap + (RT_BLOCK / 64) * RT_LEAF_WORDS_PER_WAVE;
+    uint32_t *tops = lds + (size_t)RT_BLOCK * P.stack_levels + (RT_BLOCK / 64) * RT_LEAF_WORDS_PER_WAVE;
     const uint32_t top_meshes = P.S.mesh_count < 2 ? (uint32_t)P.S.mesh_count : 2u;
     const uint32_t top_each = top_meshes ? RT_TREE_TOP / top_meshes : 0u;
     for (uint32_t m = 0; m < top_meshes; m++) {
@@ -745,29 +736,15 @@ rt_tree_kernel(const TreeParams P)
 #endif
     bool busy = false, any_hit = false;
     uint32_t slot = 0;
-    rt::f3 o = rt::mk(0, 0, 0), d = rt::mk(0, 0, 0);
     rt::Hit h; h.type = rt::HIT_NONE; h.id = 0; h.inst = 0; h.t = 0; h.beta = 0; h.gamma = 0; h.material = -1; h.entered = false;
     rt::Trav tv; memset(&tv, 0, sizeof(tv)); tv.top = -1;
-    uint32_t w15 = 0;
     uint32_t in_cur = 0, in_end = 0;
     bool input_done = false;
-#if RT_TREE_STAGE
-    uint32_t cur = RT_ENTRY_NONE;                        /* entry the lane visits next; its record is (on its way) in the lane's LDS slot */
-#else
     uint32_t cur = RT_ENTRY_NONE;                        /* entry the lane visits next; its record is in ra..rd */
     rt::u32x4 ra = 0, rb = 0, rc = 0, rd = 0;
-#endif
     bool stepped = false;                                /* the lane needs its next record */
     bool scan_wait = false;                              /* the lane's instance is done (or its ray is new): it waits to test the next instance's root box */
-#if defined(RT_ABLATE_TREE_FETCH)
-    uint32_t ablate_word = 0, ab0 = 0, ab1 = 0, ab2 = 0, ab3 = 0;
-#endif
-#if RT_TREE_SPECULATE
-    /* the records of the visited node's interior children, requested before its boxes are tested: whichever
-     * child the walk turns to next, its record has had the whole box test to arrive */
-    uint32_t spec0 = RT_ENTRY_NONE, spec1 = RT_ENTRY_NONE;
-    rt::u32x4 s0a = 0, s0b = 0, s0c = 0, s0d = 0, s1a = 0, s1b = 0, s1c = 0, s1d = 0;
-#endif
+    int depth_max = 0;                                   /* counting builds: deepest stack of the lane's ray so far */
 
 #if defined(RT_TREE_CLOCKS)      /* experiment: where a wave's time goes (one wave of the launch prints its clock counts per section) */
     unsigned long long tick[5] = {0, 0, 0, 0, 0}, tick_prev = __builtin_readcyclecounter(), tick_iterations = 0;
@@ -775,10 +752,9 @@ rt_tree_kernel(const TreeParams P)
 #else
 #define RT_TICK(i)
 #endif
-    auto finish = [&]() {                                /* answer the query: write the hit back */
-        uint4 *q = reinterpret_cast<uint4 *>(rt::ray_part(P.list, slot));
-        q[2] = make_uint4(__float_as_uint(h.t), (uint32_t)h.type, h.id, h.inst);
-        q[3] = make_uint4(__float_as_uint(h.beta), __float_as_uint(h.gamma), (uint32_t)h.material, w15);
+    auto finish = [&]() {                                /* the query is answered: whatever was accepted is in the record already */
+        if (STATS && P.depth_hist)
+            atomicAdd(reinterpret_cast<unsigned long long *>(P.depth_hist + ((uint32_t)depth_max < RT_DEPTH_BINS ? (uint32_t)depth_max : RT_DEPTH_BINS - 1u)), 1ull);
         busy = false;
     };
 
@@ -796,22 +772,19 @@ rt_tree_kernel(const TreeParams P)
                 if (in_cur >= slots) { input_done = true; break; }
                 in_end = in_cur + RT_TREE_IN_BATCH < slots ? in_cur + RT_TREE_IN_BATCH : slots;
             }
-            const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
+            const uint32_t rank = rt::bits_below_lane(need);
             const uint32_t idx = in_cur + rank;
             if (!busy && idx < in_end) {
-                const uint4 *q = reinterpret_cast<const uint4 *>(rt::ray_part(P.list, idx));
-                const uint4 a = q[0], b = q[1], c = q[2], e = q[3];
-                if ((a.x & 0x81u) == 1u) {               /* a record, and its query is not complete */
+                const uint32_t *w = rt::ray_part(P.list, idx);
+                const uint32_t flags = w[0], t_bits = w[8], w15 = w[15];
+                if ((flags & 0x81u) == 1u) {             /* a record, and its query is not complete */
                     slot = idx;
-                    any_hit = ((a.x >> 3) & 3u) == (uint32_t)rt::RAY_SHADOW;
-                    o = rt::mk(__uint_as_float(a.z), __uint_as_float(a.w), __uint_as_float(b.x));
-                    d = rt::mk(__uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
-                    h.t = __uint_as_float(c.x); h.type = (int)c.y; h.id = c.z; h.inst = c.w;
-                    h.beta = __uint_as_float(e.x); h.gamma = __uint_as_float(e.y); h.material = (int)e.z;
-                    w15 = e.w;
-                    tv.inst = (int)(e.w & 0xFFFFu) - 1;  /* walk_advance moves on to the instance the ray was parked for */
+                    any_hit = ((flags >> 3) & 3u) == (uint32_t)rt::RAY_SHADOW;
+                    h.t = __uint_as_float(t_bits);
+                    tv.inst = (int)(w15 & 0xFFFFu) - 1;  /* walk_advance moves on to the instance the ray was parked for */
                     tv.top = -1; tv.tri_cur = 0; tv.tri_end = 0;
                     cur = RT_ENTRY_NONE;
+                    depth_max = 0;
                     busy = true; scan_wait = true;       /* new rays arrive together: their first root-box test usually runs in this very iteration */
                     if (STATS) cn.root_tests--;          /* the shade kernel already counted this root test */
                 }
@@ -834,42 +807,28 @@ rt_tree_kernel(const TreeParams P)
         /* the leaf pass goes first: the node records requested at the end of the previous iteration
          * have its whole duration to arrive */
         if (run_leaf) {
-            const bool accepted = wave_leaf_pass<STATS>(P.S, want_tri, tri_mask, any_hit, h, tv, lane, lanes_below, leaf_best, leaf_marks, leaf_bary, cn);
+            h.type = rt::HIT_NONE;                       /* what this pass accepts, if anything */
+            const bool accepted = wave_leaf_pass<STATS>(P.S, want_tri, tri_mask, any_hit, h, tv, lane, leaf_best, leaf_marks, leaf_bary, cn);
             if (want_tri) {
                 stepped = true;
+                if (h.type == rt::HIT_TRIANGLE) {        /* the closest hit so far: into the record (a later, closer one overwrites it) */
+                    uint32_t *w = rt::ray_part(P.list, slot);
+                    *reinterpret_cast<uint4 *>(w + 8) = make_uint4(__float_as_uint(h.t), (uint32_t)rt::HIT_TRIANGLE, h.id, h.inst);
+                    *reinterpret_cast<uint2 *>(w + 12) = make_uint2(__float_as_uint(h.beta), __float_as_uint(h.gamma));
+                    w[14] = (uint32_t)tv.material;
+                }
                 if (accepted && any_hit) { finish(); stepped = false; }
             }
         }
         RT_TICK(1)
         if (run_node) {
             if (STATS) { if (lane == 0) cn.pop_steps++; if (want_node) cn.pop_lanes++; }
-#if RT_TREE_STAGE
-            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the records asked for at the end of the previous iteration are in LDS */
-#endif
             if (want_node) {
-#if RT_TREE_STAGE
-                const rt::u32x4 ra = my_record[0], rb = my_record[1], rc = my_record[2], rd = my_record[3];
-#endif
-#if RT_TREE_SPECULATE
-                spec0 = (rd.x & RT_ENTRY_LEAF) ? RT_ENTRY_NONE : rd.x;
-                spec1 = (rd.y & RT_ENTRY_LEAF) ? RT_ENTRY_NONE : rd.y;
-                if (spec0 != RT_ENTRY_NONE) {
-                    const rt::u32x4 *q = reinterpret_cast<const rt::u32x4 *>(P.S.nodes + tv.node_base + spec0);
-                    s0a = q[0]; s0b = q[1]; s0c = q[2]; s0d = q[3];
-                }
-                if (spec1 != RT_ENTRY_NONE) {
-                    const rt::u32x4 *q = reinterpret_cast<const rt::u32x4 *>(P.S.nodes + tv.node_base + spec1);
-                    s1a = q[0]; s1b = q[1]; s1c = q[2]; s1d = q[3];
-                }
-#endif
                 rt::walk_node<STATS>(ra, rb, rc, rd, h, tv, stk, cur, cn); stepped = true;
+                if (STATS && tv.top + 1 > depth_max) depth_max = tv.top + 1;
             }
         }
         RT_TICK(2)
-        /* ---- the one place records are requested: every lane that took a step (or a new ray) ---- */
-#if RT_TREE_STAGE
-        uint32_t want_record = RT_ENTRY_NONE;            /* index of the node record the lane needs next (none) */
-#endif
         /* lanes whose instance is done gather before the next instance's root box is tested: the test runs when enough
          * of them wait, or when the wave has little else to do */
         bool scan_now = false;
@@ -883,24 +842,21 @@ rt_tree_kernel(const TreeParams P)
                 }
             }
         }
+        /* ---- the one place records are requested: every lane that took a step (or a new ray) ---- */
         if (stepped || (scan_now && scan_wait)) {
             const bool may_scan = scan_wait;             /* a lane that has waited tests now; one that just finished its instance waits */
             stepped = false; scan_wait = false;
             const rt::u32x4 *q = nullptr;
-#if RT_TREE_SPECULATE
-            const uint32_t child = cur;                  /* the child the node step turned to (none: the stack or the next instance decide) */
-#endif
+            rt::f3 o = rt::mk(0, 0, 0), d = rt::mk(0, 0, 0);
+            if (may_scan) {                              /* origin and direction are not kept in registers between root-box tests */
+                const uint4 *r = reinterpret_cast<const uint4 *>(rt::ray_part(P.list, slot));
+                const uint4 a = r[0], b = r[1];
+                o = rt::mk(__uint_as_float(a.z), __uint_as_float(a.w), __uint_as_float(b.x));
+                d = rt::mk(__uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+            }
             const int next = rt::walk_advance<STATS>(P.S, o, d, h, tv, stk, cur, q, cn, may_scan);
             if (next == rt::NEXT_SCAN) scan_wait = true;
             if (next == rt::NEXT_NODE) {
-#if RT_TREE_STAGE
-                want_record = tv.node_base + cur;
-#else
-#if RT_TREE_SPECULATE
-                if (child != RT_ENTRY_NONE && child == spec0) { ra = s0a; rb = s0b; rc = s0c; rd = s0d; }
-                else if (child != RT_ENTRY_NONE && child == spec1) { ra = s1a; rb = s1b; rc = s1c; rd = s1d; }
-                else
-#endif
 #if RT_TREE_TOP
                 if (tv.mesh < top_meshes && cur < top_each) {
                     const rt::u32x4 *t = reinterpret_cast<const rt::u32x4 *>(tops + ((size_t)tv.mesh * top_each + cur) * 16u);
@@ -908,40 +864,14 @@ rt_tree_kernel(const TreeParams P)
                 } else
 #endif
                 { ra = q[0]; rb = q[1]; rc = q[2]; rd = q[3]; }
-#if defined(RT_ABLATE_TREE_FETCH)   /* timing experiment only: every node record is asked for twice (the second time one word per quad) */
-                {
-                    const volatile uint32_t *qv = reinterpret_cast<const volatile uint32_t *>(q);
-                    ablate_word ^= ab0 ^ ab1 ^ ab2 ^ ab3;        /* the previous step's words: long arrived */
-                    ab0 = qv[1]; ab1 = qv[5]; ab2 = qv[9]; ab3 = qv[13];
-                }
-#endif
-#endif
             }
             else if (next == rt::NEXT_DONE) finish();
-#if RT_TREE_SPECULATE
-            spec0 = spec1 = RT_ENTRY_NONE;
-#endif
         }
-#if RT_TREE_STAGE
-        /* all lanes: load i fetches the records wanted by lanes 4j + i, a quarter per lane of quad j; an owner's slot
-         * is written only by loads made for it, so a record waits there until its owner's next node step */
-        if (__ballot(want_record != RT_ENTRY_NONE)) {
-#define RT_STAGE_LOAD(i) { \
-                const uint32_t rec = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)want_record, (i) * 0x55, 0xF, 0xF, false); \
-                if (rec != RT_ENTRY_NONE) \
-                    __builtin_amdgcn_global_load_lds(nodes_words + (size_t)rec * 16u, node_stage + (i) * RT_STAGE_LOAD_WORDS, 16, 0, 0); }
-            RT_STAGE_LOAD(0) RT_STAGE_LOAD(1) RT_STAGE_LOAD(2) RT_STAGE_LOAD(3)
-#undef RT_STAGE_LOAD
-        }
-#endif
         RT_TICK(3)
 #if defined(RT_TREE_CLOCKS)
         tick_iterations++;
 #endif
     }
-#if defined(RT_ABLATE_TREE_FETCH)
-    if (ablate_word == 0x12345u && P.capacity == 7u) P.list[0] = ablate_word;     /* keeps the extra loads alive */
-#endif
 #if defined(RT_TREE_CLOCKS)
     if (blockIdx.x == 77 && threadIdx.x == 64)
         printf("tree wave: %llu iterations; clocks: refill %llu, leaf pass %llu, node step %llu, advance+request %llu\n",
@@ -1000,7 +930,6 @@ rt_finish_kernel(const FinishParams P)
     rt::PathMachine<rt::CounterRng, STATS, SPECULAR, true> pm(P.S, stk, cn);   /* box tests with the ray's shared reciprocals where they are exact */
     pm.half_w = P.half_w; pm.half_h = P.half_h; pm.max_segments = P.max_segments;
     pm.rng.seed0 = P.seed0; pm.rng.seed1 = P.seed1;
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
     uint32_t sample_index = 0;
     uint32_t in_cur = 0, in_end = 0;
     bool input_done = false;
@@ -1037,7 +966,7 @@ rt_finish_kernel(const FinishParams P)
                 if (in_cur >= slots) { input_done = true; break; }
                 in_end = in_cur + 64u < slots ? in_cur + 64u : slots;
             }
-            const uint32_t idx = in_cur + (uint32_t)__popcll(need & lanes_below);
+            const uint32_t idx = in_cur + rt::bits_below_lane(need);
             if (pm.phase == rt::PH_DEAD && idx < in_end &&
                 pm.load_record(rt::ray_part(list, idx), rt::path_part(list, P.capacity, idx), sample_index)) {
                 if (!(rt::ray_part(list, idx)[0] & 0x80u)) {   /* the query still has a tree to walk */
@@ -1072,7 +1001,7 @@ rt_finish_kernel(const FinishParams P)
             const unsigned long long tri_mask = __ballot(want_tri);
             if (tri_mask) {
                 const bool any_hit = pm.ray == rt::RAY_SHADOW;
-                const bool accepted = wave_leaf_pass<STATS>(P.S, want_tri, tri_mask, any_hit, pm.h, pm.tv, lane, lanes_below,
+                const bool accepted = wave_leaf_pass<STATS>(P.S, want_tri, tri_mask, any_hit, pm.h, pm.tv, lane,
                                                             leaf_best, leaf_marks, leaf_bary, cn);
                 if (want_tri && accepted && any_hit) pm.after_tree(rt::STEP_QUERY_DONE);
                 RT_FTICK(2, __popcll(tri_mask))
@@ -1398,6 +1327,7 @@ struct BatchLane {
     float *d_samples = nullptr; uint64_t sample_bytes = 0;     /* per-sample values between shading and the per-pixel sum */
     uint32_t *d_parked[2] = {nullptr, nullptr}; uint64_t parked_records = 0;   /* paths in transit, ping-pong */
     QueueCounters *d_rounds = nullptr;                         /* one record per round of each pass */
+    uint32_t *d_spill = nullptr;                               /* the tree launches' stack entries beyond the LDS levels (made with the lane's other work memory) */
     hipEvent_t done = nullptr;                                 /* after the lane's latest per-pixel sum */
 };
 
@@ -1405,6 +1335,7 @@ struct Knobs {                        /* environment, read once per scene handle
     uint64_t scratch_mb = 4096, parked_mb = 98304;
     uint32_t lanes = 3, max_rounds = 16, tail_lanes = 32;
     uint64_t batch_paths = 80u << 20;
+    uint32_t tree_stack = RT_TREE_STACK_LDS;   /* stack entries per ray the tree kernel keeps in LDS */
     int64_t finish_below = -1;         /* < 0: by the size of the batch */
     bool trace_rounds = false;
 };
@@ -1423,6 +1354,9 @@ struct rt_gpu_scene {
     hipStream_t host_stream = nullptr;                        /* rt_gpu_render_region (host image) orders its render here */
     Knobs knobs;
     uint32_t shade_blocks = 0, resume_blocks = 0, tree_blocks = 0, finish_blocks = 0;   /* persistent grid sizes */
+    uint32_t tree_levels = 0;                                 /* stack entries per ray in the tree kernel's LDS (the rest in a lane's d_spill) */
+    uint64_t spill_bytes = 0;                                 /* size of a lane's d_spill */
+    uint64_t *d_depth_hist = nullptr;                         /* RT_DEPTH_BINS counters: rays by deepest stack (launches with detailed counters) */
     bool specular = true;                                     /* some material is a mirror or glass */
     struct Timer { hipEvent_t first, second; int kind; };
     std::vector<Timer> timers;                                /* pending kernel timings */
@@ -1505,6 +1439,8 @@ static void free_lane(BatchLane &L)
 {
     if (L.d_samples) (void)hipFree(L.d_samples);
     for (int k = 0; k < 2; k++) if (L.d_parked[k]) (void)hipFree(L.d_parked[k]);
+    if (L.d_spill) (void)hipFree(L.d_spill);
+    L.d_spill = nullptr;
     L.d_samples = nullptr; L.sample_bytes = 0;
     L.d_parked[0] = L.d_parked[1] = nullptr; L.parked_records = 0;
 }
@@ -1550,6 +1486,7 @@ static int read_knobs(Knobs &k)
     v = k.max_rounds; if ((rc = number("RT_GPU_MAX_ROUNDS", 0, 255, v))) return rc; k.max_rounds = (uint32_t)v;
     v = k.tail_lanes; if ((rc = number("RT_GPU_TAIL_LANES", 0, 64, v))) return rc; k.tail_lanes = (uint32_t)v;
     if ((rc = number("RT_GPU_BATCH_PATHS", 64, 1ull << 40, k.batch_paths))) return rc;
+    v = k.tree_stack; if ((rc = number("RT_GPU_TREE_STACK", 1, 64, v))) return rc; k.tree_stack = (uint32_t)v;
     v = 0; if (getenv("RT_GPU_FINISH_BELOW")) { if ((rc = number("RT_GPU_FINISH_BELOW", 0, 0xFFFFFFFFull, v))) return rc; k.finish_below = (int64_t)v; }
     k.trace_rounds = getenv("RT_GPU_TRACE_ROUNDS") != nullptr;
     return 0;
@@ -1614,10 +1551,12 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
         if ((rc = upload(s, flat.attrs, &s->dev.attrs))) break;
         if ((rc = upload(s, flat.texels, &s->dev.texels))) break;
         if ((rc = read_knobs(s->knobs))) break;
-        std::vector<uint64_t> zeros(RT_KINDS * RT_STAT_WORDS + 2, 0);
+        std::vector<uint64_t> zeros(RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS, 0);
         const uint64_t *st = nullptr;
         if ((rc = upload(s, zeros, &st))) break;
         s->d_stats = const_cast<uint64_t *>(st);
+        s->d_depth_hist = s->d_stats + RT_KINDS * RT_STAT_WORDS + 2;
+        s->tree_levels = s->knobs.tree_stack < s->dev.stack_cap ? s->knobs.tree_stack : s->dev.stack_cap;
         std::vector<uint32_t> qzero(sizeof(QueueCounters) / 4, 0);
         const uint32_t *qp = nullptr;
         if ((rc = upload(s, qzero, &qp))) break;
@@ -1626,7 +1565,7 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
             const size_t lds_bytes = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
             int per_cu_shade = 0, per_cu_tree = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shade, rt_shade_kernel<true, false, true>, RT_BLOCK, RT_POOL_LDS) != hipSuccess || per_cu_shade < 1) per_cu_shade = 1;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tree, rt_tree_kernel<false>, RT_BLOCK, lds_bytes + RT_TREE_EXTRA_LDS) != hipSuccess || per_cu_tree < 1) per_cu_tree = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tree, rt_tree_kernel<false>, RT_BLOCK, (size_t)RT_BLOCK * s->tree_levels * 4 + RT_TREE_EXTRA_LDS) != hipSuccess || per_cu_tree < 1) per_cu_tree = 1;
             int per_cu_finish = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_finish, rt_finish_kernel<false, true>, RT_BLOCK, lds_bytes + RT_FINISH_EXTRA_LDS) != hipSuccess || per_cu_finish < 1) per_cu_finish = 1;
             s->finish_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_finish);
@@ -1640,6 +1579,10 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
             s->shade_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_shade);
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
+            /* one slice per thread of a tree launch for the stack entries beyond the LDS levels (at least one entry: the
+             * pointer is never null) */
+            const uint32_t deep = s->dev.stack_cap > s->tree_levels ? s->dev.stack_cap - s->tree_levels : 1u;
+            s->spill_bytes = (uint64_t)s->tree_blocks * RT_BLOCK * deep * 4u;
         }
         {   /* one stream, one record table and one event per batch lane; their work memory comes with the first render */
             bool ok = hipEventCreateWithFlags(&s->ev_start, hipEventDisableTiming) == hipSuccess &&
@@ -1696,12 +1639,13 @@ int rt_gpu_scene_set_camera(rt_gpu_scene *s, const void *camera)
 }
 
 /* work memory of one lane: grows, never shrinks; false = the device has no room (everything of the lane freed) */
-static bool ensure_lane(BatchLane &L, uint64_t sample_bytes, uint64_t parked_records)
+static bool ensure_lane(BatchLane &L, uint64_t sample_bytes, uint64_t parked_records, uint64_t spill_bytes)
 {
     if (L.sample_bytes >= sample_bytes && L.parked_records >= parked_records) return true;
     (void)hipStreamSynchronize(L.stream);
     free_lane(L);
-    bool ok = hipMalloc(reinterpret_cast<void **>(&L.d_samples), sample_bytes) == hipSuccess;
+    bool ok = hipMalloc(reinterpret_cast<void **>(&L.d_samples), sample_bytes) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&L.d_spill), spill_bytes) == hipSuccess;
     for (int k = 0; ok && k < 2; k++)
         ok = hipMalloc(reinterpret_cast<void **>(&L.d_parked[k]), parked_records * RT_RECORD_WORDS * 4) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); free_lane(L); return false; }
@@ -1937,7 +1881,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
                 if (needed <= RT_MAX_PASSES) passes = (uint32_t)needed; else ok = false;
             } else ok = false;
         }
-        for (uint32_t i = 0; ok && i < lanes_used; i++) ok = ensure_lane(s->lanes[(first_lane + i) % K.lanes], sample_bytes, capacity);
+        for (uint32_t i = 0; ok && i < lanes_used; i++) ok = ensure_lane(s->lanes[(first_lane + i) % K.lanes], sample_bytes, capacity, s->spill_bytes);
         if (ok) break;
         if (batch_spp == 1 || (frames > 1 && batch_spp == spp)) {
             if (lane_cap > 1) { lane_cap--; continue; }              /* the smallest batches: fewer of them in flight */
@@ -1952,6 +1896,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     }
 
     const size_t lds = (size_t)RT_BLOCK * s->dev.stack_cap * 4;
+    const size_t tree_lds = (size_t)RT_BLOCK * s->tree_levels * 4 + RT_TREE_EXTRA_LDS;
     const uint32_t resolve_grid = (uint32_t)((units * 64 + RT_BLOCK - 1) / RT_BLOCK);
     /* parked records at or below which one launch finishes the paths.  Measured on three scenes: a frame of
      * 1024x1024x64 (67 M paths) is shortest when the rounds stop at about a million records (the survivors of
@@ -1972,7 +1917,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     hipEvent_t previous_sum = nullptr;                   /* per-pixel sums run in batch order: a pixel's samples are added in sample order */
     for (uint64_t batch = 0, first64 = 0; first64 < total_spp; batch++, first64 += batch_spp) {
         BatchLane &L = s->lanes[(first_lane + batch % lanes_used) % K.lanes];     /* only the lanes whose work memory was made ready above */
-        if (!L.d_samples || !L.d_parked[0] || !L.d_parked[1] || !L.d_rounds) return fail(RT_GPU_ERR_DEVICE, "internal: batch lane without work memory");
+        if (!L.d_samples || !L.d_parked[0] || !L.d_parked[1] || !L.d_rounds || !L.d_spill) return fail(RT_GPU_ERR_DEVICE, "internal: batch lane without work memory");
         hipStream_t stream = L.stream;
         if (batch < lanes_used) RT_HIP(hipStreamWaitEvent(stream, s->ev_start, 0));
         const uint32_t first = (uint32_t)first64;
@@ -1995,9 +1940,10 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
                 memset(&T, 0, sizeof(T));
                 T.S = P.S; T.list = L.d_parked[(r - 1) & 1]; T.capacity = P.out_capacity; T.finish_below = finish_below;
                 T.q = Q + (r - 1); T.stats = s->d_stats + KIND_TREE * RT_STAT_WORDS;
+                T.spill = L.d_spill; T.stack_levels = s->tree_levels; T.depth_hist = s->d_depth_hist;
                 if ((rc = timed_launch(s, timed, KIND_TREE, stream, [&]() {
-                        if (detailed) hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(s->tree_blocks), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, stream, T);
-                        else hipLaunchKernelGGL(rt_tree_kernel<false>, dim3(s->tree_blocks), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, stream, T);
+                        if (detailed) hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(s->tree_blocks), dim3(RT_BLOCK), tree_lds, stream, T);
+                        else hipLaunchKernelGGL(rt_tree_kernel<false>, dim3(s->tree_blocks), dim3(RT_BLOCK), tree_lds, stream, T);
                     }))) return rc;
                 P.stats = s->d_stats + KIND_RESUME * RT_STAT_WORDS;
                 P.q_in = Q + (r - 1); P.q = Q + r;
@@ -2308,8 +2254,11 @@ static int find_ray_hit(rt_gpu_scene *s, const rt_ray *rays, uint32_t ray_count,
         (void)hipFree(d_rays);
         return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the result table");
     }
-    if (!serial && hipMalloc(reinterpret_cast<void **>(&d_list), (size_t)ray_count * RT_RECORD_WORDS * 4) != hipSuccess) {
+    uint32_t *d_spill = nullptr;
+    if (!serial && (hipMalloc(reinterpret_cast<void **>(&d_list), (size_t)ray_count * RT_RECORD_WORDS * 4) != hipSuccess ||
+                    hipMalloc(reinterpret_cast<void **>(&d_spill), s->spill_bytes) != hipSuccess)) {
         (void)hipFree(d_rays); (void)hipFree(d_res);
+        if (d_list) (void)hipFree(d_list);
         return fail(RT_GPU_ERR_MEMORY, "hipMalloc failed for the ray records");
     }
     const uint32_t grid = (ray_count + RT_BLOCK - 1) / RT_BLOCK;
@@ -2335,8 +2284,9 @@ static int find_ray_hit(rt_gpu_scene *s, const rt_ray *rays, uint32_t ray_count,
             TreeParams T;
             memset(&T, 0, sizeof(T));
             T.S = s->dev; T.list = d_list; T.capacity = ray_count; T.fixed_slots = ray_count; T.q = s->d_queue; T.stats = s->d_stats;
-            uint32_t tgrid = s->tree_blocks < grid ? s->tree_blocks : grid;
-            hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(tgrid), dim3(RT_BLOCK), lds + RT_TREE_EXTRA_LDS, nullptr, T);
+            T.spill = d_spill; T.stack_levels = s->tree_levels; T.depth_hist = s->d_depth_hist;
+            uint32_t tgrid = s->tree_blocks < grid ? s->tree_blocks : grid;      /* the spill area has a slice for every thread of tree_blocks workgroups */
+            hipLaunchKernelGGL(rt_tree_kernel<true>, dim3(tgrid), dim3(RT_BLOCK), (size_t)RT_BLOCK * s->tree_levels * 4 + RT_TREE_EXTRA_LDS, nullptr, T);
             e = hipGetLastError();
         }
         if (e == hipSuccess) {
@@ -2348,6 +2298,7 @@ static int find_ray_hit(rt_gpu_scene *s, const rt_ray *rays, uint32_t ray_count,
     if (e == hipSuccess) e = hipMemcpy(out, d_res, (size_t)ray_count * 72, hipMemcpyDeviceToHost);
     (void)hipFree(d_rays); (void)hipFree(d_res);
     if (d_list) (void)hipFree(d_list);
+    if (d_spill) (void)hipFree(d_spill);
     if (e != hipSuccess) return fail(RT_GPU_ERR_DEVICE, std::string("closest-hit probe: ") + hipGetErrorString(e));
     return RT_GPU_OK;
 }
@@ -2386,19 +2337,19 @@ static void fill_counters(rt_gpu_stats *out, const uint64_t *w)
     out->shade_lanes = w[16]; out->pop_lanes = w[17]; out->tri_lanes = w[18]; out->tree_entries = w[19];
 }
 
-static int read_stats(rt_gpu_scene *s, uint64_t w[RT_KINDS * RT_STAT_WORDS + 2])
+static int read_stats(rt_gpu_scene *s, uint64_t w[RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS])
 {
     RT_HIP(hipSetDevice(s->device));
     RT_HIP(hipDeviceSynchronize());
     settle_timers(s);
-    RT_HIP(hipMemcpy(w, s->d_stats, sizeof(uint64_t) * (RT_KINDS * RT_STAT_WORDS + 2), hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(w, s->d_stats, sizeof(uint64_t) * (RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS), hipMemcpyDeviceToHost));
     return 0;
 }
 
 int rt_gpu_get_stats(rt_gpu_scene *s, rt_gpu_stats *out)
 {
     if (!s || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_get_stats: NULL argument");
-    uint64_t w[RT_KINDS * RT_STAT_WORDS + 2];
+    uint64_t w[RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS];
     int rc = read_stats(s, w);
     if (rc) return rc;
     uint64_t sum[RT_STAT_WORDS] = {0};
@@ -2418,7 +2369,7 @@ int rt_gpu_get_stats(rt_gpu_scene *s, rt_gpu_stats *out)
 int rt_gpu_get_stats_by_kernel(rt_gpu_scene *s, rt_gpu_stats out[4])
 {
     if (!s || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_get_stats_by_kernel: NULL argument");
-    uint64_t w[RT_KINDS * RT_STAT_WORDS + 2];
+    uint64_t w[RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS];
     int rc = read_stats(s, w);
     if (rc) return rc;
     memset(out, 0, sizeof(rt_gpu_stats) * RT_KINDS);
@@ -2435,13 +2386,24 @@ int rt_gpu_get_stats_by_kernel(rt_gpu_scene *s, rt_gpu_stats out[4])
     return RT_GPU_OK;
 }
 
+int rt_gpu_get_stack_histogram(rt_gpu_scene *s, uint64_t out[32])
+{
+    if (!s || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_get_stack_histogram: NULL argument");
+    static_assert(RT_DEPTH_BINS == 32, "the header promises 32 bins");
+    uint64_t w[RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS];
+    int rc = read_stats(s, w);
+    if (rc) return rc;
+    memcpy(out, w + RT_KINDS * RT_STAT_WORDS + 2, sizeof(uint64_t) * RT_DEPTH_BINS);
+    return RT_GPU_OK;
+}
+
 int rt_gpu_reset_stats(rt_gpu_scene *s)
 {
     if (!s) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_reset_stats: NULL argument");
     RT_HIP(hipSetDevice(s->device));
     RT_HIP(hipDeviceSynchronize());
     settle_timers(s);
-    RT_HIP(hipMemset(s->d_stats, 0, sizeof(uint64_t) * (RT_KINDS * RT_STAT_WORDS + 2)));
+    RT_HIP(hipMemset(s->d_stats, 0, sizeof(uint64_t) * (RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS)));
     for (int k = 0; k < RT_KINDS; k++) s->kind_ms[k] = 0.0;
     s->launches = 0; s->passes = 0; s->samples = 0;
     return RT_GPU_OK;

@@ -15,6 +15,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "rt_host.h"
 
@@ -448,7 +449,13 @@ int rt_host_mesh_save(const rt_mesh *mesh, uint64_t key, const char *path)
     h.magic = MESH_FILE_MAGIC; h.version = MESH_FILE_VERSION;
     h.points = mesh->point_count; h.texcoords = mesh->texcoord_count; h.normals = mesh->normal_count;
     h.faces = mesh->face_count; h.nodes = cen[0]; h.tree_depth = mesh->tree_depth; h.key = key;
-    FILE *f = fopen(path, "wb");
+    /* written under a name of this process's own, then renamed over the target: processes started together that all
+     * miss and all build never read one another's half-written file */
+    size_t len = strlen(path);
+    char *tmp = malloc(len + 32);
+    if (!tmp) { free(tree); return -2; }
+    snprintf(tmp, len + 32, "%s.%ld.tmp", path, (long)getpid());
+    FILE *f = fopen(tmp, "wb");
     int ok = f != NULL;
     ok = ok && fwrite(&h, sizeof(h), 1, f) == 1;
     ok = ok && (!h.points || fwrite(mesh->points, sizeof(rt_vec3f), h.points, f) == h.points);
@@ -458,8 +465,10 @@ int rt_host_mesh_save(const rt_mesh *mesh, uint64_t key, const char *path)
     ok = ok && fwrite(tree, 32, h.nodes, f) == h.nodes;
     if (f) ok = (fclose(f) == 0) && ok;
     free(tree);
-    if (!ok) { remove(path); return -3; }
-    return 0;
+    ok = ok && rename(tmp, path) == 0;
+    if (!ok) remove(tmp);
+    free(tmp);
+    return ok ? 0 : -3;
 }
 
 /* node `*at` of the dump and its subtree back into linked records; 0 on a malformed dump */
@@ -501,9 +510,10 @@ int rt_host_mesh_load(const char *path, uint64_t key, rt_mesh *out)
     else if (!h.faces || h.faces > 0x07FFFFFFu || !h.nodes || h.nodes > 2u * h.faces + 1u || !(h.nodes & 1u)) rc = -4;
     if (!rc) {
         out->point_count = h.points; out->texcoord_count = h.texcoords; out->normal_count = h.normals; out->face_count = h.faces;
-        out->points = malloc(sizeof(rt_vec3f) * (h.points ? h.points : 1));
-        out->texcoords = malloc(sizeof(rt_vec2f) * (h.texcoords ? h.texcoords : 1));
-        out->normals = malloc(sizeof(rt_vec3f) * (h.normals ? h.normals : 1));
+        /* an attribute the file does not hold is one zeroed entry, and every id of it must then be 0 (checked below) */
+        out->points = calloc(h.points ? h.points : 1, sizeof(rt_vec3f));
+        out->texcoords = calloc(h.texcoords ? h.texcoords : 1, sizeof(rt_vec2f));
+        out->normals = calloc(h.normals ? h.normals : 1, sizeof(rt_vec3f));
         out->faces = malloc(sizeof(rt_triangle) * (size_t)h.faces);
         tree = malloc((size_t)h.nodes * 32);
         pool.cap = h.nodes; pool.nodes = calloc(pool.cap, sizeof(rt_mesh_node));
@@ -521,7 +531,7 @@ int rt_host_mesh_load(const char *path, uint64_t key, rt_mesh *out)
         for (uint32_t i = 0; i < h.faces && !rc; i++)
             for (int c = 0; c < 3; c++) {
                 const rt_vertex_ref *v = &out->faces[i].ids[c];
-                if (v->vertexId >= h.points || (h.texcoords && v->texcoordId >= h.texcoords) || (h.normals && v->normalId >= h.normals)) rc = -5;
+                if (v->vertexId >= h.points || v->texcoordId >= (h.texcoords ? h.texcoords : 1u) || v->normalId >= (h.normals ? h.normals : 1u)) rc = -5;
             }
     }
     if (!rc) {

@@ -191,7 +191,41 @@ struct Stack {
 #else
     __device__ __forceinline__ uint32_t &at(int i) const { return base[(uint32_t)i * stride]; }
 #endif
+    __device__ __forceinline__ void put(int i, uint32_t v) const { at(i) = v; }
+    __device__ __forceinline__ uint32_t get(int i) const { return at(i); }
 };
+
+/* The tree kernel's stack: the first `levels` entries of a lane in LDS as above, deeper ones in a slice of device
+ * memory of the lane's own (entry i at spill[(i - levels) * spill_stride], lanes side by side).  The stack of the
+ * walk holds only the far children of nodes where both children were entered (the near child is visited at once),
+ * so it is nearly always a few entries deep although the tree has two dozen levels: LDS is paid for the common depth,
+ * the rare deep walk costs an L2 access per entry, and the order of the entries is the stack's own either way. */
+struct TreeStack {
+    uint32_t *base;              /* LDS, this lane's entry 0 */
+    uint32_t stride;
+    uint32_t *spill;             /* wave-uniform: entry 0 of the launch's first thread; the lane's own offset is added at each use,
+                                  * so the pointer lives in scalar registers and the lane keeps one 32-bit index */
+    uint32_t spill_stride;       /* threads of the launch */
+    uint32_t thread;             /* this lane's index among them */
+    int levels;
+    __device__ __forceinline__ void put(int i, uint32_t v) const
+    {
+        if (i < levels) base[(uint32_t)i * stride] = v;
+        else spill[(uint32_t)(i - levels) * spill_stride + thread] = v;
+    }
+    __device__ __forceinline__ uint32_t get(int i) const
+    {
+        if (i < levels) return base[(uint32_t)i * stride];
+        return spill[(uint32_t)(i - levels) * spill_stride + thread];
+    }
+};
+
+/* number of set bits of a wave mask below this lane (what a running count over the lanes needs): two instructions,
+ * no per-lane mask to keep in registers */
+__device__ __forceinline__ uint32_t bits_below_lane(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
 
 /* slab test by division, src/main.c:379-386 / 404-411 */
 __device__ __forceinline__ void slab(f3 lo, f3 hi, f3 o, f3 d, float &enter, float &leave)
@@ -264,8 +298,9 @@ __device__ __forceinline__ void slab_cached(f3 lo, f3 hi, f3 o, f3 d, f3 y, floa
  * a / b, so the approximate entry and exit distances lie within that of the host's; whenever the two sides of a
  * comparison are further apart than RT_SLAB_MARGIN times their magnitudes (a margin several times the error),
  * the host's comparison has the same outcome.  Otherwise, and for rays or boxes outside the magnitudes the
- * bound is proven for, the verdict is "undecided" and the caller makes the host's test by division (a fraction
- * of a percent of the waves). */
+ * bound is proven for (direction components in [2^-40, 2^40], numerators up to 2^40, distances that are zero or at
+ * least 2^-100: below that a quotient may be subnormal and its error is absolute, not relative), the verdict is
+ * "undecided" and the caller makes the host's test by division (a fraction of a percent of the waves). */
 #ifndef RT_SLAB_APPROX
 #define RT_SLAB_APPROX 1              /* 0: root boxes are always tested by division in the shade kernels */
 #endif
@@ -289,7 +324,13 @@ __device__ __forceinline__ int root_box_verdict(f3 lo, f3 hi, f3 o, f3 d, float 
     const float ax = ax0 * rx, ay = ay0 * ry, az = az0 * rz, bx = bx0 * rx, by = by0 * ry, bz = bz0 * rz;
     const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
     const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-    if (!tame_ray || !clearly_apart(enter, leave) || !clearly_apart(enter, closest)) return BOX_UNDECIDED;
+    /* the relative error bound of an approximate distance holds for normal numbers: a distance that is neither zero nor
+     * at least 2^-100 in magnitude (a product that lands among the subnormals has an absolute, not a relative, error)
+     * leaves the verdict to the division */
+    const float tiny = 0x1p-100f;
+    const bool sound = (enter == 0.0f || __builtin_fabsf(enter) >= tiny) && (leave == 0.0f || __builtin_fabsf(leave) >= tiny) &&
+                       (closest == 0.0f || __builtin_fabsf(closest) >= tiny);
+    if (!tame_ray || !sound || !clearly_apart(enter, leave) || !clearly_apart(enter, closest)) return BOX_UNDECIDED;
     return (leave < enter || enter > closest) ? BOX_MISSED : BOX_ENTERED;
 }
 
@@ -409,9 +450,9 @@ __device__ __forceinline__ bool query_begin(const rt_dev_scene &S, f3 o, f3 d, f
 
 /* from instance tv.inst on: true = tv is set up to walk an instance, false = no instance left.
  * CACHE: prepare the per-ray reciprocals for slab_cached when ray and mesh allow it. */
-template <bool STATS, bool CACHE = false>
+template <bool STATS, bool CACHE = false, class StackT = Stack>
 __device__ __forceinline__ bool query_scan(const rt_dev_scene &S, f3 o, f3 d, const Hit &h, Trav &tv,
-                                           Stack stk, Counters &cn)
+                                           StackT stk, Counters &cn)
 {
     for (; tv.inst < S.instance_count; tv.inst++) {
         const rt_dev_instance &in = S.instances[tv.inst];
@@ -439,7 +480,7 @@ __device__ __forceinline__ bool query_scan(const rt_dev_scene &S, f3 o, f3 d, co
                         tame_or_zero(tv.mo.x) && tame_or_zero(tv.mo.y) && tame_or_zero(tv.mo.z);
             tv.inv = mk(refined_rcp(tv.mu.x), refined_rcp(tv.mu.y), refined_rcp(tv.mu.z));
         }
-        stk.at(0) = m.root_entry;
+        stk.put(0, m.root_entry);
         if (STATS) cn.tree_entries++;
         return true;
     }
@@ -545,7 +586,7 @@ template <bool STATS, bool CACHE = false>
 __device__ __forceinline__ int query_pop_step(const rt_dev_scene &S, Hit &h, Trav &tv, Stack stk, Counters &cn)
 {
     if (tv.top < 0) { tv.inst++; return STEP_INSTANCE_DONE; }
-    const uint32_t e = stk.at(tv.top--);
+    const uint32_t e = stk.get(tv.top--);
     if (e & RT_ENTRY_LEAF) {
         if (STATS) cn.leaf_pops++;
         tv.tri_cur = e & RT_ENTRY_FIRST_MASK;
@@ -556,8 +597,8 @@ __device__ __forceinline__ int query_pop_step(const rt_dev_scene &S, Hit &h, Tra
     float4 q0 = q[0], q1 = q[1], q2 = q[2];
     uint4 q3 = *reinterpret_cast<const uint4 *>(q + 3);
     if (q3.z & RT_NODE_PSEUDO) {                 /* chunks of an oversized leaf, in order, no box test */
-        stk.at(++tv.top) = q3.y;
-        stk.at(++tv.top) = q3.x;
+        stk.put(++tv.top, q3.y);
+        stk.put(++tv.top, q3.x);
         return STEP_MORE;
     }
     if (STATS) cn.interior_pops++;
@@ -573,10 +614,10 @@ __device__ __forceinline__ int query_pop_step(const rt_dev_scene &S, Hit &h, Tra
     bool h1 = (e1 < l1) && (e1 < h.t);
     if (h0 && h1) {                              /* farther child first, nearer on top; ties: child 0 on top */
         bool swap = e0 > e1;
-        stk.at(++tv.top) = swap ? q3.x : q3.y;
-        stk.at(++tv.top) = swap ? q3.y : q3.x;
-    } else if (h0) stk.at(++tv.top) = q3.x;
-    else if (h1) stk.at(++tv.top) = q3.y;
+        stk.put(++tv.top, swap ? q3.x : q3.y);
+        stk.put(++tv.top, swap ? q3.y : q3.x);
+    } else if (h0) stk.put(++tv.top, q3.x);
+    else if (h1) stk.put(++tv.top, q3.y);
     return STEP_MORE;
 }
 
@@ -594,13 +635,13 @@ __device__ __forceinline__ int query_pop_step(const rt_dev_scene &S, Hit &h, Tra
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 /* the fetched interior node: src/main.c:397-447; leaves the entry to visit next in cur (or none) */
-template <bool STATS>
-__device__ __forceinline__ void walk_node(u32x4 fa, u32x4 fb, u32x4 fc, u32x4 fd, const Hit &h, Trav &tv, Stack stk,
+template <bool STATS, class StackT = Stack>
+__device__ __forceinline__ void walk_node(u32x4 fa, u32x4 fb, u32x4 fc, u32x4 fd, const Hit &h, Trav &tv, StackT stk,
                                           uint32_t &cur, Counters &cn)
 {
     const uint32_t e0 = fd.x, e1 = fd.y;
     if (fd.z & RT_NODE_PSEUDO) {                         /* chunks of an oversized leaf, in order, no box test */
-        stk.at(++tv.top) = e1;
+        stk.put(++tv.top, e1);
         cur = e0;
         return;
     }
@@ -622,7 +663,7 @@ __device__ __forceinline__ void walk_node(u32x4 fa, u32x4 fb, u32x4 fc, u32x4 fd
     cur = RT_ENTRY_NONE;
     if (h0 && h1) {                                      /* nearer child next, farther one stacked; ties: child 0 first */
         const bool swap = n0 > n1;
-        stk.at(++tv.top) = swap ? e0 : e1;
+        stk.put(++tv.top, swap ? e0 : e1);
         cur = swap ? e1 : e0;
     } else if (h0) cur = e0;
     else if (h1) cur = e1;
@@ -683,8 +724,8 @@ enum : int { NEXT_DONE = 0, NEXT_NODE = 1, NEXT_LEAF = 2, NEXT_SCAN = 3 };
  * now; it returns NEXT_SCAN unchanged and the caller lets such lanes gather (the test of an instance's root
  * box -- two table records, a transform, six divisions -- is long, and run for the one or two lanes that
  * finish an instance in a given step it costs the wave as much as a step of all its lanes) */
-template <bool STATS>
-__device__ __forceinline__ int walk_advance(const rt_dev_scene &S, f3 o, f3 d, const Hit &h, Trav &tv, Stack stk,
+template <bool STATS, class StackT = Stack>
+__device__ __forceinline__ int walk_advance(const rt_dev_scene &S, f3 o, f3 d, const Hit &h, Trav &tv, StackT stk,
                                             uint32_t &cur, const u32x4 *&addr, Counters &cn, bool may_scan = true)
 {
     if (cur == RT_ENTRY_NONE) {
@@ -694,7 +735,7 @@ __device__ __forceinline__ int walk_advance(const rt_dev_scene &S, f3 o, f3 d, c
             tv.inst++;
             if (!query_scan<STATS, true>(S, o, d, h, tv, stk, cn)) return NEXT_DONE;
         }
-        cur = stk.at(tv.top--);
+        cur = stk.get(tv.top--);
     }
     if (!(cur & RT_ENTRY_LEAF)) {
         addr = reinterpret_cast<const u32x4 *>(S.nodes + tv.node_base + cur);

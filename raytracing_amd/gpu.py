@@ -26,7 +26,7 @@ EXPORTS = [
     "rt_gpu_normalize_device", "rt_gpu_render_jobs", "rt_gpu_find_ray_hit", "rt_gpu_find_ray_hit_serial", "rt_gpu_quantize", "rt_gpu_quantize_device",
     "rt_gpu_multi_create", "rt_gpu_multi_destroy", "rt_gpu_multi_device_count", "rt_gpu_multi_render_frame",
     "rt_gpu_multi_rows_per_rank", "rt_gpu_assemble_bands_device",
-    "rt_gpu_get_stats", "rt_gpu_get_stats_by_kernel", "rt_gpu_reset_stats", "rt_gpu_eval_math",
+    "rt_gpu_get_stats", "rt_gpu_get_stats_by_kernel", "rt_gpu_reset_stats", "rt_gpu_get_stack_histogram", "rt_gpu_eval_math",
 ]
 
 
@@ -110,6 +110,7 @@ def lib():
         L.rt_gpu_assemble_bands_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.rt_gpu_get_stats_by_kernel.argtypes = [C.c_void_p, C.POINTER(Stats * 4)]
         L.rt_gpu_reset_stats.argtypes = [C.c_void_p]
+        L.rt_gpu_get_stack_histogram.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 32)]
         L.rt_gpu_eval_math.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
         _LIB = L
     return _LIB
@@ -195,6 +196,13 @@ class GpuScene:
 
     def reset_stats(self):
         _check(lib().rt_gpu_reset_stats(self._h))
+
+    def stack_histogram(self):
+        """Tree walks by deepest traversal stack (entry k: never more than k entries; 31 = 31 or more), from the calls
+        with FLAG_DETAILED_STATS and the closest-hit probes since the last reset."""
+        out = (C.c_uint64 * 32)()
+        _check(lib().rt_gpu_get_stack_histogram(self._h, C.byref(out)))
+        return [int(v) for v in out]
 
 
 class MultiGpuFrame:

@@ -136,7 +136,10 @@ def _load_mesh(name, tree="reference", leaf_triangles=0):
                 digest = hashlib.sha256(f.read() + f"|{tree}|{leaf_triangles}|v1".encode()).digest()
             content_key = int.from_bytes(digest[:8], "little")
             path = os.path.join(cache_dir, f"{name}-{tree}-{leaf_triangles}-{digest[:8].hex()}.rtmesh")
-            mesh = host.mesh_load(path, content_key)
+            try:
+                mesh = host.mesh_load(path, content_key)
+            except RuntimeError:             # a damaged cache file is a miss: rebuild and write it anew
+                mesh = None
         if mesh is None:
             with np.load(source, allow_pickle=False) as z:
                 mesh = host.mesh_from_obj_arrays(

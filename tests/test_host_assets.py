@@ -268,3 +268,53 @@ def test_prepared_mesh_file_round_trip(tmp_path, monkeypatch):
     second = scenes.load_cat_mesh()
     assert sha(host.mesh_dump_tree(first)) == sha(host.mesh_dump_tree(second))
     assert sha(host.mesh_faces_array(first)) == sha(host.mesh_faces_array(second))
+
+
+def test_prepared_mesh_file_without_an_attribute_and_a_damaged_cache(tmp_path, monkeypatch):
+    """A file whose header says it holds no normals (or texture coordinates) comes back with one zeroed entry for that
+    attribute, and every id of it must be 0: a face naming normal 3 of a file without normals is refused (-5).  A damaged
+    file in the scene helpers' cache directory is a miss, not an error: the mesh is rebuilt and the file replaced; and
+    a save leaves no temporary file behind."""
+    import struct
+    p = np.array([[0, 0, 0], [0, 0, 0], [4, 0, 0], [4, 4, 1], [0, 4, 0]], np.float32)
+    ids = np.array([[1, 0, 1], [2, 0, 1], [3, 0, 1], [4, 0, 1]], np.uint32)
+    mesh = host.mesh_from_obj_arrays(p, np.zeros((1, 2), np.float32), np.array([[0, 0, 0], [0, 0, 1]], np.float32), ids,
+                                     np.array([4], np.uint32))
+    path = str(tmp_path / "quad.rtmesh")
+    host.mesh_save(mesh, 7, path)
+    assert [f.name for f in tmp_path.iterdir()] == ["quad.rtmesh"]
+    data = bytearray(open(path, "rb").read())
+    # header: magic, version, points, texcoords, normals, faces, nodes, tree_depth (32-bit each), ..., key
+    magic, version, points, texcoords, normals, faces = struct.unpack_from("<6I", data, 0)
+    assert (points, texcoords, normals, faces) == (5, 1, 2, 2)
+    arrays_at = 64
+    normals_at = arrays_at + 12 * points + 8 * texcoords
+    without = bytearray(data[:normals_at] + data[normals_at + 12 * normals:])     # the same file with the normal array cut out ...
+    struct.pack_into("<I", without, 16, 0)                                         # ... and a header that says so
+    cut = str(tmp_path / "no-normals.rtmesh")
+    open(cut, "wb").write(bytes(without))
+    with pytest.raises(RuntimeError, match="-5"):                                  # the faces still name normal 1
+        host.mesh_load(cut, 7)
+    faces_at = normals_at
+    for f in range(faces):
+        for c in range(3):
+            struct.pack_into("<I", without, faces_at + 36 * f + 12 * c + 8, 0)     # normalId of every corner -> 0
+    open(cut, "wb").write(bytes(without))
+    back = host.mesh_load(cut, 7)
+    assert back.normal_count == 0 and back.face_count == 2
+    n0 = np.ctypeslib.as_array(C.cast(back.normals, C.POINTER(C.c_float)), shape=(3,))
+    assert (n0 == 0).all()
+    host.lib().rt_host_mesh_free(C.byref(back))
+
+    monkeypatch.setenv("RT_ASSET_CACHE_DIR", str(tmp_path / "cache"))
+    monkeypatch.setattr(scenes, "_ASSET_CACHE", {})
+    first = scenes.load_cat_mesh()
+    cached = list((tmp_path / "cache").iterdir())
+    assert len(cached) == 1
+    good = cached[0].read_bytes()
+    cached[0].write_bytes(good[: len(good) // 3])                                  # another process died half-way through
+    monkeypatch.setattr(scenes, "_ASSET_CACHE", {})
+    second = scenes.load_cat_mesh()
+    assert sha(host.mesh_dump_tree(first)) == sha(host.mesh_dump_tree(second))
+    assert cached[0].read_bytes() == good
+    assert [f.name for f in (tmp_path / "cache").iterdir()] == [cached[0].name]
