@@ -593,7 +593,10 @@ def main():
                 "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                 "frame_checksum_seed0": checksum,
                 "frame_checksums_timed": timed_checksums,
-                "passes_per_batch": round(timed_stats["passes"] / max(1, timed_stats["launches"]), 2),
+                "passes_per_batch": round(timed_stats["passes_with_work"] / max(1, timed_stats["launches"]), 2),
+                "passes_enqueued_per_batch": round(timed_stats["passes"] / max(1, timed_stats["launches"]), 2),
+                "parked_lists": "sized for every path of a batch" if timed_stats["lists_full"] else
+                                "the handle's starting size (RT_GPU_PARKED_PERCENT, default 40 % of the worst case); no batch needed a second pass",
                 "work_memory_bytes": int(g.info()["work_bytes"]),
             },
             "roofline": roofline,

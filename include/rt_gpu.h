@@ -102,8 +102,13 @@ typedef struct rt_gpu_stats {
                               * batch's paths start in several passes, so 0; if not, rt_gpu_get_stats fails) */
     uint32_t launches;       /* render calls x sample batches */
     uint32_t passes;         /* launch sequences enqueued for those batches by rt_gpu_render_region_device: one per batch
-                              * when the lists of paths in transit hold every path of the batch, up to 8 when the memory
-                              * budgets or the device leave them smaller (the new paths of a batch then start in turns) */
+                              * when the lists of paths in transit hold every path of the batch, up to 8 when they are
+                              * smaller (the new paths of a batch then start in turns); a pass that finds no path left to
+                              * start returns at once */
+    uint32_t passes_with_work;   /* ... and how many of them started paths: equal to `launches` as long as one pass per batch does */
+    uint32_t lists_full;     /* 1: the handle's lists are sized for every path of a batch.  A handle starts with lists of
+                              * RT_GPU_PARKED_PERCENT (default 40) of that size; the first batch that needs a second pass
+                              * makes the handle's later calls allocate full lists (up to RT_GPU_PARKED_MB and the free memory) */
 } rt_gpu_stats;
 
 /* Library / device ------------------------------------------------------- */
@@ -265,6 +270,10 @@ int rt_gpu_get_stack_histogram(rt_gpu_scene *scene, uint64_t out[32]);
 int rt_gpu_eval_math(const float *x, const float *y, size_t n,
                      float *sin_out, float *cos_out, float *log_out, float *div_out, float *sqrt_out,
                      float *div_cached_out);
+/* Self-test hook: n vectors (xyz, 3n floats) -> each vector divided by its length (3n floats) and the length
+ * (n floats) as the path code computes them; the reference's normalize and norm (src/math.c:21-40: one square
+ * root, three divisions) give the same bits. */
+int rt_gpu_eval_unit(const float *xyz, size_t n, float *unit_out, float *length_out);
 
 #ifdef __cplusplus
 }

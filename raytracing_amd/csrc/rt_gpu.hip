@@ -22,6 +22,7 @@
 
 #define RT_BLOCK 256                 /* 4 waves per workgroup */
 #define RT_STAT_WORDS 20
+#define RT_TOTAL_WORDS 3              /* after the per-kind counters: rounds that had work, paths lost to a full list, passes that started paths */
 #ifndef RT_SHADE_WEIGHT
 #define RT_SHADE_WEIGHT 16            /* in-wave scheduler (job replay, finish kernel): weight of a lane that wants a
                                        * shade step, in 1/16ths of a lane that wants a tree step */
@@ -110,7 +111,7 @@ struct QueueCounters {
     uint32_t overflow;               /* paths that found the output list full (cannot happen: see ShadeParams.out_limit) */
     uint32_t parked;                 /* records actually parked (out_reserved counts whole chunks) */
     uint32_t tree_next;              /* cursor of the tree launch that answers this round's records */
-    uint32_t pad[2];
+    uint32_t pad[2];                 /* [0]: round 0 only: the pass found paths to start */
 };
 
 struct ShadeParams {
@@ -127,6 +128,9 @@ struct ShadeParams {
                                       * slots reserved (a reservation returns the count of all waves; what the waves hold and take until
                                       * they reserve again still fits); the portions left wait for the next pass.  0: no limit */
     uint32_t finish_below;           /* resume: the round runs only if more records than this were parked (else the finishing launch takes them) */
+    uint32_t *more_passes;           /* new paths, second and later passes of a batch: set to 1 (host memory) when the pass finds paths to start,
+                                      * i.e. the lists were too small for one pass; NULL in a batch's first pass */
+    uint64_t *pass_count;            /* new paths: += 1 per pass that finds paths to start */
     uint32_t chunk;                  /* new paths: output slots a wave reserves per atomic (<= RT_CHUNK, multiple of 64) */
     uint32_t tail_lanes;             /* a wave left with fewer paths than this and no input hands them to the next round (0: never) */
     uint32_t width, height;          /* image */
@@ -197,6 +201,10 @@ rt_shade_kernel(const ShadeParams P)
         chunk = records >= (4u << 20) ? RT_CHUNK : RT_SMALL_CHUNK;
     } else if (__builtin_amdgcn_readfirstlane(*P.portion_next) >= P.blocks_x * P.block_rows * ((P.launch_spp + RT_PORTION_SPP - 1u) / RT_PORTION_SPP)) {
         return;                                          /* an earlier pass started every path of the batch */
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {    /* the launch's first workgroup sees the cursor before the launch has moved it far */
+        P.q->pad[0] = 1u;                                /* this pass has work (the finishing launch counts its rounds) */
+        if (P.pass_count) atomicAdd(reinterpret_cast<unsigned long long *>(P.pass_count), 1ull);
+        if (P.more_passes) __hip_atomic_store(P.more_passes, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     rt::Stack stk; stk.base = nullptr; stk.stride = 0;                      /* this kernel walks no tree */
     rt::Counters cn; memset(&cn, 0, sizeof(cn));
@@ -364,7 +372,14 @@ rt_shade_kernel(const ShadeParams P)
         pool_n += (uint32_t)__popcll(pushing);
     };
 
+#if defined(RT_SHADE_CLOCKS)
+    unsigned long long stick[16]; for (int i = 0; i < 16; i++) stick[i] = 0;
+    stick[15] = __builtin_readcyclecounter();
+    pm.ticks = stick;
+    unsigned long long stick_steps = 0, stick_lanes = 0;
+#endif
     for (;;) {
+        RT_STICK(stick, 7)
         /* ---- 1. give free lanes a path ----------------------------------------- */
         if (FRESH) {
             const unsigned long long need = __ballot(!has);
@@ -390,6 +405,7 @@ rt_shade_kernel(const ShadeParams P)
                 pool_n -= take;
             }
         }
+        RT_STICK(stick, 0)
         /* ---- 2. one shade step ---------------------------------------------------- */
         /* Lanes about to do the same kind of step run together: a step's cost is dominated by the
          * code of its kind (book a surface hit / book a light sample, then a light-sample or bounce
@@ -446,6 +462,10 @@ rt_shade_kernel(const ShadeParams P)
         }
         if (FRESH && !__ballot(has)) break;              /* nothing in flight and no input left */
         const bool go = has && kind_of() == best;
+        RT_STICK(stick, 1)
+#if defined(RT_SHADE_CLOCKS)
+        stick_steps++; stick_lanes += (unsigned long long)__popcll(__ballot(go));
+#endif
         if (STATS) { if (lane == 0) cn.shade_steps++; if (go) cn.shade_lanes++; }
         if (go) {
             pm.shade_step_park([&]() {
@@ -457,6 +477,7 @@ rt_shade_kernel(const ShadeParams P)
             });
         }
 
+        RT_STICK(stick, 6)
         if (!FRESH) {                                    /* what was asked for during the last step has long arrived */
             stage_land();
             if (__popcll(~(ready | flight)) - (64 - (int)RT_SLOTS) >= RT_STAGE_REFILL && !(cursor_done && in_cur >= in_end)) stage_issue();
@@ -482,6 +503,11 @@ rt_shade_kernel(const ShadeParams P)
             }
         }
     }
+#if defined(RT_SHADE_CLOCKS)
+    if (blockIdx.x == 77 && threadIdx.x == 64)
+        printf("shade wave (fresh %d): %llu steps, %.1f lanes; clocks: take paths/camera %llu, pick kind %llu, book %llu, event %llu, primitives %llu, root boxes %llu, step end %llu, park + staging %llu\n",
+               (int)FRESH, stick_steps, (double)stick_lanes / (double)(stick_steps ? stick_steps : 1), stick[0], stick[1], stick[2], stick[3], stick[4], stick[5], stick[6], stick[7]);
+#endif
     /* unused tail of the last reserved chunk: mark the slots empty */
     for (uint32_t slot = out_cur + lane; slot < out_end && slot < P.out_capacity; slot += 64)
         *rt::ray_part(P.out_list, slot) = 0u;
@@ -917,7 +943,7 @@ rt_finish_kernel(const FinishParams P)
     QueueCounters *q = P.rounds + round;
     const uint32_t reserved = __builtin_amdgcn_readfirstlane(q->out_reserved);
     const uint32_t slots = reserved < P.capacity ? reserved : P.capacity;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && P.totals) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.totals && P.rounds[0].pad[0]) {
         atomicAdd(reinterpret_cast<unsigned long long *>(P.totals), (unsigned long long)(round + 1u));
         if (lost) atomicAdd(reinterpret_cast<unsigned long long *>(P.totals + 1), (unsigned long long)lost);
     }
@@ -1258,7 +1284,18 @@ __global__ void rt_math_kernel(const float *x, const float *y, size_t n, float *
     if (l) l[i] = rt_logf(x[i]);
     if (q && y) q[i] = x[i] / y[i];
     if (qc && y) qc[i] = (rt::tame(y[i]) && rt::tame_or_zero(x[i])) ? rt::div_by_cached(x[i], y[i], rt::refined_rcp(y[i])) : x[i] / y[i];
-    if (r) r[i] = __builtin_sqrtf(x[i]);
+    if (r) r[i] = rt::sqrt_rn(x[i]);
+}
+
+/* v[3i..3i+2] -> its normalisation and its length as the path code computes them (rt::unit) */
+__global__ void rt_unit_kernel(const float *v, size_t n, float *u, float *len)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float length;
+    const rt::f3 r = rt::unit(rt::mk(v[3 * i], v[3 * i + 1], v[3 * i + 2]), length);
+    u[3 * i] = r.x; u[3 * i + 1] = r.y; u[3 * i + 2] = r.z;
+    len[i] = length;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1318,6 +1355,7 @@ static int static_scratch_of(int device, unsigned char **out)
 enum { KIND_FRESH = 0, KIND_RESUME = 1, KIND_TREE = 2, KIND_FINISH = 3 };
 #define RT_MAX_LANES 8
 #define RT_MAX_PASSES 8               /* passes over a batch whose parked lists are smaller than the batch */
+#define RT_EXTRA_PASS_ROUNDS 6u       /* rounds enqueued for the second and later passes */
 
 /* Work memory of one batch of samples in flight: a frame's batches go round-robin over the lanes,
  * each on its own stream, so the latency-bound last rounds of one batch run beside the
@@ -1333,7 +1371,8 @@ struct BatchLane {
 
 struct Knobs {                        /* environment, read once per scene handle */
     uint64_t scratch_mb = 4096, parked_mb = 98304;
-    uint32_t lanes = 3, max_rounds = 16, tail_lanes = 32;
+    uint32_t lanes = 3, max_rounds = 12, tail_lanes = 32;
+    uint32_t parked_percent = 40;      /* size of the lists of paths in transit a handle starts with, in percent of what every path of a batch would need */
     uint64_t batch_paths = 80u << 20;
     uint32_t tree_stack = RT_TREE_STACK_LDS;   /* stack entries per ray the tree kernel keeps in LDS */
     int64_t finish_below = -1;         /* < 0: by the size of the batch */
@@ -1364,6 +1403,8 @@ struct rt_gpu_scene {
     double kind_ms[RT_KINDS] = {0.0, 0.0, 0.0, 0.0};
     uint32_t launches = 0, passes = 0;
     uint64_t samples = 0;
+    uint32_t *more_passes = nullptr, *d_more_passes = nullptr;   /* one word of pinned host memory and its device address: a batch needed a second pass */
+    bool lists_full = false;                                  /* the lanes' lists are sized for every path of a batch from now on */
     double create_ms[2] = {0.0, 0.0};                         /* flatten, allocate + upload */
     uint64_t resident_bytes = 0;
 };
@@ -1458,6 +1499,7 @@ void rt_gpu_scene_destroy(rt_gpu_scene *s)
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
+    if (s->more_passes) (void)hipHostFree(s->more_passes);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->host_stream) (void)hipStreamDestroy(s->host_stream);
     for (auto &t : s->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
@@ -1484,6 +1526,7 @@ static int read_knobs(Knobs &k)
     if ((rc = number("RT_GPU_PARKED_MB", 1, 1u << 20, k.parked_mb))) return rc;
     v = k.lanes; if ((rc = number("RT_GPU_STREAMS", 1, RT_MAX_LANES, v))) return rc; k.lanes = (uint32_t)v;
     v = k.max_rounds; if ((rc = number("RT_GPU_MAX_ROUNDS", 0, 255, v))) return rc; k.max_rounds = (uint32_t)v;
+    v = k.parked_percent; if ((rc = number("RT_GPU_PARKED_PERCENT", 1, 100, v))) return rc; k.parked_percent = (uint32_t)v;
     v = k.tail_lanes; if ((rc = number("RT_GPU_TAIL_LANES", 0, 64, v))) return rc; k.tail_lanes = (uint32_t)v;
     if ((rc = number("RT_GPU_BATCH_PATHS", 64, 1ull << 40, k.batch_paths))) return rc;
     v = k.tree_stack; if ((rc = number("RT_GPU_TREE_STACK", 1, 64, v))) return rc; k.tree_stack = (uint32_t)v;
@@ -1551,11 +1594,11 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
         if ((rc = upload(s, flat.attrs, &s->dev.attrs))) break;
         if ((rc = upload(s, flat.texels, &s->dev.texels))) break;
         if ((rc = read_knobs(s->knobs))) break;
-        std::vector<uint64_t> zeros(RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS, 0);
+        std::vector<uint64_t> zeros(RT_KINDS * RT_STAT_WORDS + RT_TOTAL_WORDS + RT_DEPTH_BINS, 0);
         const uint64_t *st = nullptr;
         if ((rc = upload(s, zeros, &st))) break;
         s->d_stats = const_cast<uint64_t *>(st);
-        s->d_depth_hist = s->d_stats + RT_KINDS * RT_STAT_WORDS + 2;
+        s->d_depth_hist = s->d_stats + RT_KINDS * RT_STAT_WORDS + RT_TOTAL_WORDS;
         s->tree_levels = s->knobs.tree_stack < s->dev.stack_cap ? s->knobs.tree_stack : s->dev.stack_cap;
         std::vector<uint32_t> qzero(sizeof(QueueCounters) / 4, 0);
         const uint32_t *qp = nullptr;
@@ -1594,6 +1637,17 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
                      hipMalloc(reinterpret_cast<void **>(&L.d_rounds), sizeof(QueueCounters) * (s->knobs.max_rounds + 1) * RT_MAX_PASSES) == hipSuccess;
             }
             if (!ok) { rc = fail(RT_GPU_ERR_DEVICE, "could not create the streams, events and round records of the batch lanes"); break; }
+        }
+        {   /* one word the device can write and the host can read without a copy: "a batch needed a second pass" */
+            void *host_word = nullptr, *dev_word = nullptr;
+            if (hipHostMalloc(&host_word, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dev_word, host_word, 0) != hipSuccess) {
+                if (host_word) (void)hipHostFree(host_word);
+                rc = fail(RT_GPU_ERR_DEVICE, "could not map a word of host memory for the device");
+                break;
+            }
+            s->more_passes = static_cast<uint32_t *>(host_word); s->d_more_passes = static_cast<uint32_t *>(dev_word);
+            *s->more_passes = 0u;
+            s->lists_full = s->knobs.parked_percent >= 100;
         }
         {   /* this device's address of the static work memory (rt_gpu_render_region_static), asked once per device */
             unsigned char *unused = nullptr;
@@ -1813,6 +1867,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     if (batch_spp > total_spp) batch_spp = total_spp;
     if (batch_spp * items_per_sample > 0xFFFFFF00ull / 3) batch_spp = (0xFFFFFF00ull / 3) / items_per_sample;
     if (batch_spp < 1) return fail(RT_GPU_ERR_ARGUMENT, "region too large for one launch");
+    if (!s->lists_full && __atomic_load_n(s->more_passes, __ATOMIC_RELAXED)) s->lists_full = true;   /* an earlier batch of this handle needed a second pass */
     size_t free_bytes = 0, device_bytes = 0;
     if (hipMemGetInfo(&free_bytes, &device_bytes) != hipSuccess) { (void)hipGetLastError(); free_bytes = ~(size_t)0; }
     uint64_t held = 0;
@@ -1864,15 +1919,24 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
         uint64_t allowed = lists_bytes / (2 * record_bytes) / RT_CHUNK * RT_CHUNK;       /* slots of either list */
         if (allowed > 0xFFFFFF00ull) allowed = 0xFFFFFF00ull;
         capacity = full; passes = 1; out_limit = 0;
+        /* a wave learns how full the list is when it reserves a chunk of it.  Once the limit is passed a wave
+         * can still fill the chunk it has, take one more portion of new paths, park all of them and the paths
+         * its lanes and its pool hold (the first of these reservations tells it to stop), and leave a chunk
+         * partly used; the resumed-path launches park no more records than they were given, plus a partly
+         * used chunk per wave */
+        const uint64_t after_look = shade_waves * (RT_CHUNK + 64u * RT_PORTION_SPP + 64u + RT_POOL + RT_CHUNK);
+        const uint64_t margin = after_look + resume_waves * RT_CHUNK;
+        const uint64_t padding = shade_waves * RT_CHUNK;             /* reserved slots that hold no record */
+        if (!s->lists_full) {
+            /* Lists for every path of the batch are the worst case (a scene whose every path walks a tree at once);
+             * in the room scenes a quarter of the paths is in transit at most.  A handle therefore starts with lists
+             * of parked_percent of that size, the passes being the safety net, and only a handle whose batch really
+             * needed a second pass (the device says so in `more_passes`) gets full lists from its next call on.
+             * Batches so small that the waves' margins would eat the saving keep full lists. */
+            const uint64_t modest = (full * K.parked_percent / 100 + RT_CHUNK - 1) / RT_CHUNK * RT_CHUNK;
+            if (modest >= 2 * (margin + 2 * padding) && modest < allowed) allowed = modest;
+        }
         if (ok && full > allowed) {
-            /* a wave learns how full the list is when it reserves a chunk of it.  Once the limit is passed a wave
-             * can still fill the chunk it has, take one more portion of new paths, park all of them and the paths
-             * its lanes and its pool hold (the first of these reservations tells it to stop), and leave a chunk
-             * partly used; the resumed-path launches park no more records than they were given, plus a partly
-             * used chunk per wave */
-            const uint64_t after_look = shade_waves * (RT_CHUNK + 64u * RT_PORTION_SPP + 64u + RT_POOL + RT_CHUNK);
-            const uint64_t margin = after_look + resume_waves * RT_CHUNK;
-            const uint64_t padding = shade_waves * RT_CHUNK;             /* reserved slots that hold no record */
             capacity = allowed;
             if (capacity > margin + 2 * padding) {
                 out_limit = capacity - margin;
@@ -1928,14 +1992,19 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
         P.portion_next = &L.d_rounds[0].unit_next;       /* the passes of a batch share the cursor over its new paths */
         for (uint32_t pass = 0; pass < passes; pass++) {
             QueueCounters *Q = L.d_rounds + (size_t)pass * (rounds + 1);      /* the pass's round records */
+            /* the second and later passes are the safety net of lists smaller than the batch: they get fewer rounds
+             * (an unneeded launch costs 3.6 us; whatever their last round leaves is the finishing launch's) */
+            const uint32_t pass_rounds = pass == 0 || rounds < RT_EXTRA_PASS_ROUNDS ? rounds : RT_EXTRA_PASS_ROUNDS;
             /* round 0: new paths */
             P.stats = s->d_stats + KIND_FRESH * RT_STAT_WORDS;
             P.q = Q; P.q_in = nullptr; P.in_list = nullptr; P.out_list = L.d_parked[0];
             P.chunk = RT_CHUNK;
+            P.pass_count = s->d_stats + RT_KINDS * RT_STAT_WORDS + 2;
+            P.more_passes = pass > 0 && !s->lists_full ? s->d_more_passes : nullptr;
             if ((rc = timed_launch(s, timed, KIND_FRESH, stream, [&]() { launch_shade(true, detailed, s->specular, shade_grid, stream, P); }))) return rc;
             /* rounds 1 ...: answer the parked queries, resume those paths.  What a round has to do stands in
              * the previous round's record; launches of rounds that are not needed return at once. */
-            for (uint32_t r = 1; r <= rounds; r++) {
+            for (uint32_t r = 1; r <= pass_rounds; r++) {
                 TreeParams T;
                 memset(&T, 0, sizeof(T));
                 T.S = P.S; T.list = L.d_parked[(r - 1) & 1]; T.capacity = P.out_capacity; T.finish_below = finish_below;
@@ -1954,7 +2023,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
             FinishParams F;
             memset(&F, 0, sizeof(F));
             F.S = P.S; F.lists[0] = L.d_parked[0]; F.lists[1] = L.d_parked[1]; F.capacity = P.out_capacity;
-            F.rounds = Q; F.last_round = rounds; F.finish_below = finish_below;
+            F.rounds = Q; F.last_round = pass_rounds; F.finish_below = finish_below;
             F.totals = s->d_stats + RT_KINDS * RT_STAT_WORDS;
             F.samples = P.samples; F.stats = s->d_stats + KIND_FINISH * RT_STAT_WORDS;
             F.seed0 = P.seed0; F.seed1 = P.seed1; F.max_segments = P.max_segments; F.half_w = P.half_w; F.half_h = P.half_h;
@@ -1990,7 +2059,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
             RT_HIP(hipStreamSynchronize(stream));
             RT_HIP(hipMemcpy(q.data(), L.d_rounds, sizeof(QueueCounters) * q.size(), hipMemcpyDeviceToHost));
             for (uint32_t pass = 0; pass < passes; pass++)
-                for (uint32_t r = 0; r <= rounds; r++) {
+                for (uint32_t r = 0; r <= (pass == 0 || rounds < RT_EXTRA_PASS_ROUNDS ? rounds : RT_EXTRA_PASS_ROUNDS); r++) {
                     const QueueCounters &c = q[(size_t)pass * (rounds + 1) + r];
                     fprintf(stderr, "batch %llu pass %u round %u: parked %u records in %u slots of %llu%s\n", (unsigned long long)batch, pass, r, c.parked,
                             c.out_reserved, (unsigned long long)capacity, c.parked <= finish_below ? " -> finishing launch" : "");
@@ -2337,19 +2406,19 @@ static void fill_counters(rt_gpu_stats *out, const uint64_t *w)
     out->shade_lanes = w[16]; out->pop_lanes = w[17]; out->tri_lanes = w[18]; out->tree_entries = w[19];
 }
 
-static int read_stats(rt_gpu_scene *s, uint64_t w[RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS])
+static int read_stats(rt_gpu_scene *s, uint64_t w[RT_KINDS * RT_STAT_WORDS + RT_TOTAL_WORDS + RT_DEPTH_BINS])
 {
     RT_HIP(hipSetDevice(s->device));
     RT_HIP(hipDeviceSynchronize());
     settle_timers(s);
-    RT_HIP(hipMemcpy(w, s->d_stats, sizeof(uint64_t) * (RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS), hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(w, s->d_stats, sizeof(uint64_t) * (RT_KINDS * RT_STAT_WORDS + RT_TOTAL_WORDS + RT_DEPTH_BINS), hipMemcpyDeviceToHost));
     return 0;
 }
 
 int rt_gpu_get_stats(rt_gpu_scene *s, rt_gpu_stats *out)
 {
     if (!s || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_get_stats: NULL argument");
-    uint64_t w[RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS];
+    uint64_t w[RT_KINDS * RT_STAT_WORDS + RT_TOTAL_WORDS + RT_DEPTH_BINS];
     int rc = read_stats(s, w);
     if (rc) return rc;
     uint64_t sum[RT_STAT_WORDS] = {0};
@@ -2362,6 +2431,7 @@ int rt_gpu_get_stats(rt_gpu_scene *s, rt_gpu_stats *out)
     out->fresh_ms = s->kind_ms[KIND_FRESH]; out->finish_ms = s->kind_ms[KIND_FINISH];
     out->rounds = w[RT_KINDS * RT_STAT_WORDS]; out->overflowed = w[RT_KINDS * RT_STAT_WORDS + 1];
     out->launches = s->launches; out->passes = s->passes;
+    out->passes_with_work = (uint32_t)w[RT_KINDS * RT_STAT_WORDS + 2]; out->lists_full = s->lists_full ? 1u : 0u;
     if (out->overflowed) return fail(RT_GPU_ERR_DEVICE, "parked-path list overflow (" + std::to_string(out->overflowed) + " paths lost): the frames since the last reset are incomplete");
     return RT_GPU_OK;
 }
@@ -2369,7 +2439,7 @@ int rt_gpu_get_stats(rt_gpu_scene *s, rt_gpu_stats *out)
 int rt_gpu_get_stats_by_kernel(rt_gpu_scene *s, rt_gpu_stats out[4])
 {
     if (!s || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_get_stats_by_kernel: NULL argument");
-    uint64_t w[RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS];
+    uint64_t w[RT_KINDS * RT_STAT_WORDS + RT_TOTAL_WORDS + RT_DEPTH_BINS];
     int rc = read_stats(s, w);
     if (rc) return rc;
     memset(out, 0, sizeof(rt_gpu_stats) * RT_KINDS);
@@ -2377,6 +2447,7 @@ int rt_gpu_get_stats_by_kernel(rt_gpu_scene *s, rt_gpu_stats out[4])
         fill_counters(out + k, w + k * RT_STAT_WORDS);
         out[k].kernel_ms = s->kind_ms[k];
         out[k].launches = s->launches; out[k].passes = s->passes;
+        out[k].passes_with_work = (uint32_t)w[RT_KINDS * RT_STAT_WORDS + 2]; out[k].lists_full = s->lists_full ? 1u : 0u;
     }
     out[KIND_FRESH].shade_ms = out[KIND_FRESH].fresh_ms = s->kind_ms[KIND_FRESH];
     out[KIND_RESUME].shade_ms = s->kind_ms[KIND_RESUME];
@@ -2390,10 +2461,10 @@ int rt_gpu_get_stack_histogram(rt_gpu_scene *s, uint64_t out[32])
 {
     if (!s || !out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_get_stack_histogram: NULL argument");
     static_assert(RT_DEPTH_BINS == 32, "the header promises 32 bins");
-    uint64_t w[RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS];
+    uint64_t w[RT_KINDS * RT_STAT_WORDS + RT_TOTAL_WORDS + RT_DEPTH_BINS];
     int rc = read_stats(s, w);
     if (rc) return rc;
-    memcpy(out, w + RT_KINDS * RT_STAT_WORDS + 2, sizeof(uint64_t) * RT_DEPTH_BINS);
+    memcpy(out, w + RT_KINDS * RT_STAT_WORDS + RT_TOTAL_WORDS, sizeof(uint64_t) * RT_DEPTH_BINS);
     return RT_GPU_OK;
 }
 
@@ -2403,7 +2474,7 @@ int rt_gpu_reset_stats(rt_gpu_scene *s)
     RT_HIP(hipSetDevice(s->device));
     RT_HIP(hipDeviceSynchronize());
     settle_timers(s);
-    RT_HIP(hipMemset(s->d_stats, 0, sizeof(uint64_t) * (RT_KINDS * RT_STAT_WORDS + 2 + RT_DEPTH_BINS)));
+    RT_HIP(hipMemset(s->d_stats, 0, sizeof(uint64_t) * (RT_KINDS * RT_STAT_WORDS + RT_TOTAL_WORDS + RT_DEPTH_BINS)));
     for (int k = 0; k < RT_KINDS; k++) s->kind_ms[k] = 0.0;
     s->launches = 0; s->passes = 0; s->samples = 0;
     return RT_GPU_OK;
@@ -2434,6 +2505,29 @@ int rt_gpu_eval_math(const float *x, const float *y, size_t n, float *sin_out, f
         if (d[i]) e = hipMemcpy(hout[i - 2], d[i], n * sizeof(float), hipMemcpyDeviceToHost);
     for (int i = 0; i < 8; i++) if (d[i]) (void)hipFree(d[i]);
     if (e != hipSuccess) return fail(RT_GPU_ERR_DEVICE, std::string("math probe: ") + hipGetErrorString(e));
+    return RT_GPU_OK;
+}
+
+int rt_gpu_eval_unit(const float *xyz, size_t n, float *unit_out, float *length_out)
+{
+    if (!xyz || !unit_out || !length_out) return fail(RT_GPU_ERR_ARGUMENT, "rt_gpu_eval_unit: NULL argument");
+    if (!n) return RT_GPU_OK;
+    float *d_in = nullptr, *d_unit = nullptr, *d_len = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_in), 3 * n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_unit), 3 * n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_len), n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_in, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rt_unit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d_in, n, d_unit, d_len);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(unit_out, d_unit, 3 * n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(length_out, d_len, n * sizeof(float), hipMemcpyDeviceToHost);
+    if (d_in) (void)hipFree(d_in);
+    if (d_unit) (void)hipFree(d_unit);
+    if (d_len) (void)hipFree(d_len);
+    if (e != hipSuccess) return fail(RT_GPU_ERR_DEVICE, std::string("unit probe: ") + hipGetErrorString(e));
     return RT_GPU_OK;
 }
 

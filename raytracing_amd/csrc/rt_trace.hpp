@@ -32,6 +32,12 @@
 #define RT_DOUBLE 0
 #endif
 #define RT_OPAQUE(x) __asm__ volatile("" : "+v"(x))
+/* RT_SHADE_CLOCKS (timing experiment): one wave of a shade launch prints the clock counts of the sections of its loop */
+#if defined(RT_SHADE_CLOCKS)
+#define RT_STICK(t, i) { const unsigned long long now_ = __builtin_readcyclecounter(); (t)[i] += now_ - (t)[15]; (t)[15] = now_; }
+#else
+#define RT_STICK(t, i)
+#endif
 namespace rt {
 
 struct f3 { float x, y, z; };
@@ -55,8 +61,74 @@ __device__ __forceinline__ float dot(f3 a, f3 b)
     return r;
 }
 __device__ __forceinline__ float len2(f3 a) { return dot(a, a); }
-__device__ __forceinline__ float len(f3 a) { return __builtin_sqrtf(len2(a)); }
-__device__ __forceinline__ f3 unit(f3 a) { float n = len(a); return mk(a.x / n, a.y / n, a.z / n); }
+
+/* ---- correctly rounded square root and the three quotients of a normalisation, without the parts of
+ * hipcc's expansions that only serve operands of extreme magnitude --------------------------------
+ *
+ * hipcc expands sqrtf(x) into: scale x by 2^32 when x < 2^-96; s = v_sqrt_f32(x) (within one unit in the
+ * last place); the two neighbours of s tested with one fma each (s - 1ulp if fma(-(s - 1ulp), s, x) <= 0,
+ * s + 1ulp if fma(-(s + 1ulp), s, x) > 0); unscale; x itself for zero and infinity.  The middle part alone
+ * returns the same value whenever no scaling takes place, zero, infinity and NaN included (the neighbours'
+ * residuals are then NaN or zero and select nothing): sixteen instructions become nine.  RT_LEAN_MATH=0
+ * keeps the compiler's expansions everywhere. */
+#ifndef RT_LEAN_MATH
+#define RT_LEAN_MATH 1
+#endif
+/* precondition: x is +0, +infinity, NaN, or a positive number of at least 2^-96 */
+__device__ __forceinline__ float sqrt_unscaled(float x)
+{
+#if RT_LEAN_MATH
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_below = __builtin_fmaf(-below, s, x), r_above = __builtin_fmaf(-above, s, x);
+    float r = (0.0f >= r_below) ? below : s;
+    r = (0.0f < r_above) ? above : r;
+    return r;
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
+/* any operand: the short form for positive numbers from 2^-96 up to infinity (one integer comparison of the
+ * bits); zeros, smaller and negative numbers, NaNs take the compiler's expansion (v_sqrt_f32 flushes
+ * subnormal operands, negative ones to -0) */
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+#if RT_LEAN_MATH
+    if (__float_as_uint(x) - 0x0F800000u <= 0x7F800000u - 0x0F800000u) return sqrt_unscaled(x);
+#endif
+    return __builtin_sqrtf(x);
+}
+__device__ __forceinline__ float len(f3 a) { return sqrt_rn(len2(a)); }
+
+__device__ __forceinline__ float refined_rcp(float b);
+__device__ __forceinline__ float div_by_cached(float a, float b, float y1);
+/* a / |a| as the host computes it (src/math.c:29-40: one square root, three divisions by it).  The three
+ * divisions share their divisor, so the part of the division's expansion that depends on the divisor only is
+ * done once (div_by_cached below: the same operations as hipcc's expansion, hence the same bits) whenever the
+ * expansion's scaling and special cases cannot apply: squared length in [2^-60, 2^60] (then the length is a
+ * normal number in [2^-30, 2^30]) and every component zero or at least 2^-63 in magnitude (v_frexp_exp gives 0
+ * for a zero, exponent + 1 otherwise), so every quotient is zero or at least 2^-93.  A zero component keeps its
+ * sign as in the host's quotient by a positive number (the shared form alone could turn -0 into +0).
+ * 42 instructions with one reciprocal instead of 54 with three. */
+__device__ __forceinline__ f3 unit(f3 a, float &length)
+{
+    const float n2 = len2(a);
+#if RT_LEAN_MATH
+    const int ex = __builtin_amdgcn_frexp_expf(a.x), ey = __builtin_amdgcn_frexp_expf(a.y), ez = __builtin_amdgcn_frexp_expf(a.z);
+    const int emin = ex < ey ? (ex < ez ? ex : ez) : (ey < ez ? ey : ez);
+    if (__float_as_uint(n2) - 0x21800000u <= 0x5D800000u - 0x21800000u && emin >= -62) {
+        const float n = sqrt_unscaled(n2);
+        const float y = refined_rcp(n);
+        length = n;
+        return mk(__builtin_copysignf(div_by_cached(a.x, n, y), a.x), __builtin_copysignf(div_by_cached(a.y, n, y), a.y),
+                  __builtin_copysignf(div_by_cached(a.z, n, y), a.z));
+    }
+#endif
+    const float n = __builtin_sqrtf(n2);
+    length = n;
+    return mk(a.x / n, a.y / n, a.z / n);
+}
+__device__ __forceinline__ f3 unit(f3 a) { float n; return unit(a, n); }
 __device__ __forceinline__ f3 add(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ f3 sub(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ f3 mul(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
@@ -344,7 +416,7 @@ __device__ __forceinline__ bool ball(f3 center, float radius, f3 o, f3 d, float 
     float c = len2(oc) - radius * radius;
     float det = b * b - c;
     if (det < 0.0f) return false;
-    float root = __builtin_sqrtf(det);
+    float root = sqrt_rn(det);
     float t = -b - root;
     if (t < 1e-3f) t = -b + root;      /* the host compares with the double 1e-3: same set of floats */
     else entered = true;
@@ -925,7 +997,7 @@ struct PathMachine {
         f3 c = mk(0.0f, 0.0f, 0.0f);
         if (!(lights_reached == 0)) c = scale(radiance, 1 / lights_reached);
         float c2 = len2(c);
-        if (c2 > 1e4f) c = scale(c, (float)(1e2 / (double)__builtin_sqrtf(c2)));
+        if (c2 > 1e4f) c = scale(c, (float)(1e2 / (double)sqrt_unscaled(c2)));
         return c;
     }
 
@@ -982,7 +1054,7 @@ struct PathMachine {
                         d = sub(across, along);
                     } else {
                         inside_glass = !inside_glass;
-                        f3 forward = scale(unit(along), __builtin_sqrtf(1 - b2));
+                        f3 forward = scale(unit(along), sqrt_rn(1 - b2));
                         d = add(forward, bent);
                     }
                     if (segment_budget_left()) ev = EV_TRACE_ONLY; else ended = true;
@@ -1043,7 +1115,7 @@ struct PathMachine {
 #endif                      /* Box-Muller radius^2, src/math.c:230 */
         else if (ev == EV_NEE) arg = 2 * u1 - u1 * u1;                    /* src/main.c:555 */
         else arg = 1 - u1;                                                /* src/main.c:696 */
-        float ring = __builtin_sqrtf(arg);
+        float ring = sqrt_unscaled(arg);                /* arg is zero, infinite or at least 2^-24: u1 is a multiple of 2^-23 */
         if (ev == EV_CAMERA) {
             if (STATS) cn.samples++;
             float jx = 0.0f + 0.25f * cs * ring;
@@ -1063,7 +1135,7 @@ struct PathMachine {
                 c0 = -(1 - u1);
             } else {
                 axis = n;
-                c0 = __builtin_sqrtf(u1);
+                c0 = sqrt_unscaled(u1);
             }
             f3 t0 = frame_tangent(axis);
             f3 t1 = cross(axis, t0);
@@ -1071,12 +1143,13 @@ struct PathMachine {
             if (ev == EV_NEE) {
                 f3 q = scale(v, S.lights[li].radius);
                 f3 path = sub(add(q, lc), o);
-                f3 dir = unit(path);
+                float path_len;
+                f3 dir = unit(path, path_len);
                 shadow_cos = dot(dir, n);
                 if (!(shadow_cos < 0)) {
                     d = dir;
                     shadow_len2 = len2(path);
-                    tmax = __builtin_sqrtf(shadow_len2);
+                    tmax = path_len;                                      /* norm(path), src/main.c:597 */
                     ray = RAY_SHADOW;
                 }
             } else {
@@ -1185,13 +1258,17 @@ struct PathMachine {
     /* shade step of the shade kernel: as shade_step, but a ray that enters an
      * instance's root box is not walked here: the lane asks to be parked
      * (PH_PARK, park_inst) and the tree kernel finishes the query. */
+    unsigned long long *ticks = nullptr;   /* RT_SHADE_CLOCKS only */
     template <class OnEnd>
     __device__ __forceinline__ void shade_step_park(OnEnd &&on_end)
     {
         if (book()) on_end();
+        RT_STICK(ticks, 2)
         if (phase == PH_SHADE) {
             float tmax;
-            if (event(tmax)) on_end();
+            const bool ended_ = event(tmax);
+            RT_STICK(ticks, 3)
+            if (ended_) on_end();
             else if (ray != RAY_NONE) {
                 if (RT_EARLY_OUT(STATS)) {
                     if (!query_begin<STATS>(S, o, d, tmax, ray == RAY_SHADOW, h, cn)) {
@@ -1202,6 +1279,7 @@ struct PathMachine {
                     /* the root boxes are tested whether or not the primitives already answered the query: some lane
                      * of the wave needs the test anyway, and one straight run of code beats a branch around it */
                     const bool answered = query_begin<STATS>(S, o, d, tmax, ray == RAY_SHADOW, h, cn);
+                    RT_STICK(ticks, 4)
 #if RT_DOUBLE == 4
                     {
                         Hit h2; f3 o2 = o; RT_OPAQUE(o2.x);
@@ -1219,6 +1297,7 @@ struct PathMachine {
                     }
 #endif
                     if (!answered && park_inst >= 0) phase = PH_PARK;
+                    RT_STICK(ticks, 5)
                 }
             }
         }

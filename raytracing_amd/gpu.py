@@ -26,7 +26,7 @@ EXPORTS = [
     "rt_gpu_normalize_device", "rt_gpu_render_jobs", "rt_gpu_find_ray_hit", "rt_gpu_find_ray_hit_serial", "rt_gpu_quantize", "rt_gpu_quantize_device",
     "rt_gpu_multi_create", "rt_gpu_multi_destroy", "rt_gpu_multi_device_count", "rt_gpu_multi_render_frame",
     "rt_gpu_multi_rows_per_rank", "rt_gpu_assemble_bands_device",
-    "rt_gpu_get_stats", "rt_gpu_get_stats_by_kernel", "rt_gpu_reset_stats", "rt_gpu_get_stack_histogram", "rt_gpu_eval_math",
+    "rt_gpu_get_stats", "rt_gpu_get_stats_by_kernel", "rt_gpu_reset_stats", "rt_gpu_get_stack_histogram", "rt_gpu_eval_math", "rt_gpu_eval_unit",
 ]
 
 
@@ -48,7 +48,8 @@ class Stats(C.Structure):
         "tri_tests", "tri_hits", "tex_lookups", "rng_draws", "light_tests", "sphere_tests", "plane_tests",
         "shade_steps", "pop_steps", "tri_steps", "shade_lanes", "pop_lanes", "tri_lanes", "tree_entries")] + [
         ("kernel_ms", C.c_double), ("shade_ms", C.c_double), ("tree_ms", C.c_double), ("fresh_ms", C.c_double), ("finish_ms", C.c_double),
-        ("rounds", C.c_uint64), ("overflowed", C.c_uint64), ("launches", C.c_uint32), ("passes", C.c_uint32)]
+        ("rounds", C.c_uint64), ("overflowed", C.c_uint64), ("launches", C.c_uint32), ("passes", C.c_uint32),
+        ("passes_with_work", C.c_uint32), ("lists_full", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -112,6 +113,7 @@ def lib():
         L.rt_gpu_reset_stats.argtypes = [C.c_void_p]
         L.rt_gpu_get_stack_histogram.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 32)]
         L.rt_gpu_eval_math.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
+        L.rt_gpu_eval_unit.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -251,6 +253,14 @@ def quantize(pixels):
 def quantize_device(device_pixels_ptr, pixel_count, device_rgb_ptr, stream=0):
     """Device float RGB -> device RGB8 (the display transfer of the reference's save_image)."""
     _check(lib().rt_gpu_quantize_device(device_pixels_ptr, pixel_count, device_rgb_ptr, C.c_void_p(stream)))
+
+
+def eval_unit(v):
+    """Device normalisation of the rows of an (n, 3) float array: (unit vectors, lengths) (self-test hook)."""
+    v = np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 3)
+    unit, length = np.zeros_like(v), np.zeros(len(v), dtype=np.float32)
+    _check(lib().rt_gpu_eval_unit(v.ctypes.data, len(v), unit.ctypes.data, length.ctypes.data))
+    return unit, length
 
 
 def eval_math(x, y=None):

@@ -83,6 +83,52 @@ def test_device_math_equals_host_math(golden):
             assert same.all(), int((~same).sum())
 
 
+def test_device_normalisation_equals_host_arithmetic():
+    """The path code's normalisation (one square root, three quotients that share the refined reciprocal of the
+    length) and its square root without the scaling steps against the host's arithmetic
+    (sqrtf and three IEEE divisions, src/math.c:21-40), bit for bit: vectors of every magnitude from the
+    subnormals to overflow, zero components of either sign, components 60 orders of magnitude apart,
+    exact and near-exact quotients, the special values."""
+    rng = np.random.default_rng(7)
+    n = 1 << 21
+    parts = []
+    for lo, hi in ((-3, 3), (-35, 35), (-70, 70), (-150, 128)):
+        v = (rng.standard_normal((n, 3)) * 2.0 ** rng.uniform(lo, hi, (n, 3))).astype(np.float32)
+        v[::7, 2] = 0.0
+        v[::11, 1] = -0.0
+        v[::13, 0] = 0.0
+        parts.append(v)
+    v = (rng.standard_normal((n, 3)) * 2.0 ** rng.uniform(-20, 20, (n, 1))).astype(np.float32)    # components of like size
+    v[::5] = np.round(v[::5] * 8) / 8
+    v[::3, 0] = (v[::3, 0].view(np.uint32) | np.uint32(0x007FFFFF)).view(np.float32)
+    parts.append(v)
+    k = rng.integers(-8, 9, (n, 3)).astype(np.float32)                                                # exact lengths (3, 4, 0 ...)
+    parts.append(k * np.float32(2.0) ** rng.integers(-40, 40, (n, 1)).astype(np.float32))
+    special = np.array([0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 3e38, -1e-38, 1.0, 3.0, 2.0 ** -63, 2.0 ** -64, 2.0 ** -30, 2.0 ** 30], np.float32)
+    grid = np.stack(np.meshgrid(special, special, special, indexing="ij"), -1).reshape(-1, 3)
+    parts.append(grid)
+    v = np.concatenate(parts).astype(np.float32)
+    got_unit, got_len = gpu.eval_unit(v)
+    with np.errstate(all="ignore"):
+        # the host's dot product: ((0 + x*x) + y*y) + z*z in binary32, then sqrtf, then three divisions
+        n2 = (np.float32(0) + v[:, 0] * v[:, 0])
+        n2 = n2 + v[:, 1] * v[:, 1]
+        n2 = n2 + v[:, 2] * v[:, 2]
+        want_len = np.sqrt(n2)
+        want_unit = v / want_len[:, None]
+    same_len = L.same_bits(got_len, want_len) | (np.isnan(got_len) & np.isnan(want_len))
+    assert same_len.all(), (int((~same_len).sum()), v[~same_len][:4])
+    same = L.same_bits(got_unit, want_unit) | (np.isnan(got_unit) & np.isnan(want_unit))
+    assert same.all(), (int((~same).sum()), v[~same.all(axis=1)][:4])
+    # the square root alone: every magnitude, the scaled range below 2^-96 included
+    x = np.abs(rng.standard_normal(1 << 22) * 2.0 ** rng.uniform(-149, 128, 1 << 22)).astype(np.float32)
+    x[:14] = special
+    with np.errstate(all="ignore"):
+        got, want = gpu.eval_math(x)["sqrt"], np.sqrt(x)
+    same = L.same_bits(got, want) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), (int((~same).sum()), x[~same][:4])
+
+
 def test_device_display_transfer_equals_host_arithmetic(gpu_scenes):
     """rt_gpu_quantize_device (save_image's min / power / x255 / truncation on device pixels,
     src/main.c:73-82) against the same arithmetic on the host (rt_gamma_byte), byte for byte:
@@ -804,6 +850,49 @@ def test_lists_smaller_than_a_batch_start_its_paths_in_passes(gpu_scenes, monkey
     assert st2["overflowed"] == 0 and st2["rays"] == 2 * st["rays"]
     assert small.info()["work_bytes"] < 4 << 30
     small.close()
+
+
+def test_lists_start_small_and_grow_when_a_batch_needs_a_second_pass(monkeypatch):
+    """A handle starts with lists of paths in transit of 40 % of the worst case (every path of the batch
+    parked at once).  The dog room parks a quarter of its paths: one pass, the lists stay.  Dogs and cat parks
+    five paths of six: the first frame takes several passes (same pixels), the device tells the host, and the
+    handle's next call has full lists and one pass again."""
+    import torch
+    W = H = 1024
+    spp, seed = 48, 99                       # 50 M paths: large enough for the smaller lists to be used
+    a = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    b = torch.zeros_like(a)
+    monkeypatch.setenv("RT_GPU_STREAMS", "1")
+    light = gpu.GpuScene(scenes.dog_room())
+    light.render_region_device(a.data_ptr(), W, H, (0, 0, W, H), spp, seed)
+    torch.cuda.synchronize()
+    light.render_region_device(a.data_ptr(), W, H, (0, 0, W, H), spp, seed)
+    torch.cuda.synchronize()
+    st = light.stats()
+    assert st["launches"] == 2 and st["passes_with_work"] == 2 and st["passes"] > 2 and st["lists_full"] == 0, st
+    small_bytes = light.info()["work_bytes"]
+    light.close()
+    heavy = gpu.GpuScene(scenes.dogs_and_cat())
+    heavy.render_region_device(a.data_ptr(), W, H, (0, 0, W, H), spp, seed)
+    torch.cuda.synchronize()
+    st1 = heavy.stats()
+    assert st1["launches"] == 1 and st1["passes_with_work"] > 1 and st1["overflowed"] == 0, st1
+    assert heavy.info()["work_bytes"] == small_bytes
+    heavy.reset_stats()
+    heavy.render_region_device(b.data_ptr(), W, H, (0, 0, W, H), spp, seed)
+    torch.cuda.synchronize()
+    st2 = heavy.stats()
+    assert st2["launches"] == 1 and st2["passes"] == 1 and st2["passes_with_work"] == 1 and st2["lists_full"] == 1, st2
+    assert st2["rays"] == st1["rays"]
+    assert heavy.info()["work_bytes"] > 2 * small_bytes
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    heavy.close()
+    monkeypatch.setenv("RT_GPU_PARKED_PERCENT", "100")
+    full = gpu.GpuScene(scenes.dog_room())
+    full.render_region_device(b.data_ptr(), W, H, (0, 0, W, H), spp, seed)
+    torch.cuda.synchronize()
+    assert full.stats()["passes"] == 1 and full.stats()["lists_full"] == 1
+    full.close()
 
 
 def test_surface_area_tree_scene(gpu_scenes):
