@@ -56,6 +56,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X vector fp32 spec peak (256 CUs x 128 lanes x 2 x 2.4 GHz)
 # vector issue: a 64-lane instruction occupies a SIMD-32 for 2 cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 2
 VALU_ISSUE_PEAK_GINST = 256 * 4 * 2.4 / 2
+SIMD_COUNT = 256 * 4
+SHADER_CLOCK_HZ = 2.4e9
 KINDS = ("new_paths", "resumed_paths", "tree", "finish")
 KERNEL_OF = {"new_paths": "rt_shade_kernel<true, false, *>", "resumed_paths": "rt_shade_kernel<false, false, *>",
              "tree": "rt_tree_kernel<false>", "finish": "rt_finish_kernel<false, *>"}
@@ -154,6 +156,24 @@ def load_counters(args, W, H, spp):
     return cj if cj.get("workload") == f"{args.scene} {W}x{H} {spp} spp" else None
 
 
+def cycle_estimate(c, seconds):
+    """Share of the vector units' cycles that the counted instructions of one kind of launch fill, with the kernel's static
+    mix priced by measured issue costs (profiles/isa_cycles.json: 2 / 4 / 8 cycles per 64-lane instruction by opcode and
+    operand kind): instructions x cycles per instruction / (launch time x 1024 SIMDs x 2.4 GHz).  An estimate: the static
+    mix of the kernel stands in for the executed one."""
+    path = os.path.join(ROOT, "profiles", "isa_cycles.json")
+    if not os.path.exists(path) or not c.get("kernel_names") or seconds <= 0:
+        return {}
+    with open(path) as f:
+        table = json.load(f)["kernels"]
+    cpis = [table[n]["cycles_per_instruction"] for n in c["kernel_names"] if n in table]
+    if not cpis:
+        return {}
+    cpi = sum(cpis) / len(cpis)
+    return {"valu_cycles_per_instruction_static": round(cpi, 3),
+            "valu_cycle_frac_estimate": round(c["valu_wave_instructions"] * cpi / (seconds * SIMD_COUNT * SHADER_CLOCK_HZ), 4)}
+
+
 def instruction_mix(c, rays):
     """Vector instructions of one kind of launch per ray of the frame, from the SQ_INSTS_VALU* counters: 64-lane issue
     slots (wave instructions x 64), the slots on active lanes, and the slots by class (f32 add / multiply / fma come almost
@@ -224,6 +244,7 @@ def secondary_scene(name, W, H, spp, seed, max_segments):
                           "lanes_active_per_valu_instruction": c.get("lanes_active"),
                           "hbm_GBs": round(hbm / sec / 1e9, 1), "hbm_frac": round(hbm / sec / 1e9 / HBM_PEAK_GBS, 4)})
                 e.update(instruction_mix(c, rays))
+                e.update(cycle_estimate(c, sec))
     g.close()
     return out
 
@@ -508,6 +529,7 @@ def main():
                           "lanes_active_per_valu_instruction": c.get("lanes_active"),
                           "hbm_bytes_per_frame": int(hbm), "hbm_GBs": round(hbm / max(1e-9, kind_ms[i] * 1e-3) / 1e9, 1),
                           "hbm_frac": round(hbm / max(1e-9, kind_ms[i] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+                e.update(cycle_estimate(c, kind_ms[i] * 1e-3))
             kernels[k] = e
         # the dominant kernel: the kind whose launches are the longest (its average launch with work); by share of the
         # frame the launch that starts the paths and the six tree launches together are within a few percent of each other
@@ -523,8 +545,13 @@ def main():
             "peak": round(VALU_ISSUE_PEAK_GINST, 1),
             "unit": "G wave-instructions/s (64-lane vector instructions issued)",
             "frac": dk.get("valu_issue_frac"),
-            "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per 64-lane instruction; a loop of independent "
-                         "v_fma_f32 (tools/micro/pk_rate.hip) reaches 900",
+            "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per 64-lane instruction.  Measured per opcode "
+                         "(tools/micro/issue_cost.hip, profiles/r3c_issue_cost.txt): only fp32 / integer add, subtract, multiply, fma, "
+                         "move, and, or, xor on vector-register operands issue in 2 cycles (1060-1190 G/s); compares, selects, min / max, "
+                         "conversions, fp64, cross-lane operations and every instruction with a scalar-register operand take 4 "
+                         "(600 G/s), transcendentals 8 (300 G/s).  valu_cycle_frac_estimate prices the kernel's static mix with "
+                         "those costs",
+            "valu_cycle_frac_estimate": dk.get("valu_cycle_frac_estimate"),
             "traffic": dk.get("hbm_bytes_per_frame"),
             "counters_source": counters["source"] if counters else None,
             "kernel_ms": round(kernel_ms, 3),

@@ -28,6 +28,7 @@ def kind_of(name):
 
 
 sums = collections.defaultdict(lambda: collections.defaultdict(float))
+names = collections.defaultdict(set)
 frames = 0
 for path in paths:
     seen = set()
@@ -36,6 +37,7 @@ for path in paths:
         if not k:
             continue
         sums[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        names[k].add(r["Kernel_Name"].split("(")[0].replace("void ", "").strip())
         if k == "new_paths":
             seen.add(r["Dispatch_Id"])
     frames = frames or len(seen)
@@ -55,12 +57,13 @@ for k, c in sums.items():
     for name in sorted(c):
         if name.startswith(("TCP_", "TCC_", "SQ_INSTS_", "SQ_INST_")) and name != "SQ_INSTS_VALU":
             e[name] = c[name] / frames
+    e["kernel_names"] = sorted(names[k])
     kinds[k] = e
 json.dump({
     "workload": workload,
     "frames_averaged": frames,
     "source": f"profiles/{tag}_pmc_*.csv.gz (raw) and .txt (per-kernel sums): rocprofv3 --pmc, one pass per counter group, of `python3 bench.py --steps 1 --warmup 0 "
-              "--no-cpu-baseline --no-side-measurements --frames-in-flight 1`; per frame and kind of launch; FETCH_SIZE and WRITE_SIZE in KiB x 1024, raw "
+              "--no-cpu-baseline --no-side-measurements --frames-in-flight 1` (the mesh-heavy scene: of `python3 tools/one_frame.py`), RT_GPU_PARKED_PERCENT=100; per frame and kind of launch; FETCH_SIZE and WRITE_SIZE in KiB x 1024, raw "
               "(the read counter tallies 128-byte requests at 64 bytes on gfx950: bench.py doubles it)",
     "kinds": kinds,
 }, sys.stdout, indent=1)

@@ -22,7 +22,9 @@ for counters in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE
                 "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32" \
                 "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"; do
   n=$((n+1))
-  timeout -s KILL 150 rocprofv3 --pmc $counters -d "$out/pmc_$n" -o pmc --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-side-measurements --frames-in-flight 1 > "$out/pmc_$n.log" 2>&1 || { echo "pmc pass $n ($counters) failed"; tail -5 "$out/pmc_$n.log"; continue; }
+  # RT_GPU_PARKED_PERCENT=100: one launch that starts paths per frame (the default smaller lists enqueue safety-net passes whose
+  # empty launches make_counters_json.py would count as frames); the counters of the launches with work are the same
+  RT_GPU_PARKED_PERCENT=100 timeout -s KILL 150 rocprofv3 --pmc $counters -d "$out/pmc_$n" -o pmc --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-side-measurements --frames-in-flight 1 > "$out/pmc_$n.log" 2>&1 || { echo "pmc pass $n ($counters) failed"; tail -5 "$out/pmc_$n.log"; continue; }
   f=$(find "$out/pmc_$n" -name '*counter_collection.csv' | head -1)
   cp "$f" "$out/pmc_$n.csv"
   python3 tools/pmc_summary.py "$f" > "$out/pmc_$n.txt"
