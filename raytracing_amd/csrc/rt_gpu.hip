@@ -778,9 +778,16 @@ rt_tree_kernel(const TreeParams P)
 #else
 #define RT_TICK(i)
 #endif
+    /* counting builds: the histogram of deepest stacks is kept per workgroup in LDS and added to the device's at the end
+     * (one global atomic per ray on 32 addresses made the counting launch fifty times as long as the plain one) */
+    __shared__ uint32_t depth_bins[STATS ? RT_DEPTH_BINS : 1u];
+    if (STATS) {
+        if (threadIdx.x < RT_DEPTH_BINS) depth_bins[threadIdx.x] = 0u;
+        __syncthreads();
+    }
     auto finish = [&]() {                                /* the query is answered: whatever was accepted is in the record already */
         if (STATS && P.depth_hist)
-            atomicAdd(reinterpret_cast<unsigned long long *>(P.depth_hist + ((uint32_t)depth_max < RT_DEPTH_BINS ? (uint32_t)depth_max : RT_DEPTH_BINS - 1u)), 1ull);
+            atomicAdd(depth_bins + ((uint32_t)depth_max < RT_DEPTH_BINS ? (uint32_t)depth_max : RT_DEPTH_BINS - 1u), 1u);
         busy = false;
     };
 
@@ -897,6 +904,11 @@ rt_tree_kernel(const TreeParams P)
 #if defined(RT_TREE_CLOCKS)
         tick_iterations++;
 #endif
+    }
+    if (STATS && P.depth_hist) {
+        __syncthreads();
+        if (threadIdx.x < RT_DEPTH_BINS && depth_bins[threadIdx.x])
+            atomicAdd(reinterpret_cast<unsigned long long *>(P.depth_hist + threadIdx.x), (unsigned long long)depth_bins[threadIdx.x]);
     }
 #if defined(RT_TREE_CLOCKS)
     if (blockIdx.x == 77 && threadIdx.x == 64)

@@ -852,6 +852,46 @@ def test_lists_smaller_than_a_batch_start_its_paths_in_passes(gpu_scenes, monkey
     small.close()
 
 
+@pytest.mark.parametrize("levels", [1, 3])
+def test_short_traversal_stack_spills_in_order(gpu_scenes, monkeypatch, levels):
+    """The tree kernel keeps a few stack entries per ray in LDS (8 by default) and deeper ones in device memory
+    (src/main.c:393-395 sizes the stack for the whole depth of the tree).  With only 1 or 3 entries in LDS
+    most walks use the spilled part: same pixels as the oracle, same probes as the one-by-one walk, the same
+    traversal counters as the default handle; and the histogram of deepest stacks shows that the default 8
+    entries are exceeded by a few walks of an ordinary render too (so that path runs in every frame)."""
+    sh, _ = gpu_scenes("dogs_and_cat")
+    monkeypatch.setenv("RT_GPU_FINISH_BELOW", "0")           # rounds of tree launches to the last path (a small frame would otherwise go to the finishing launch at once)
+    gs = gpu.GpuScene(sh)
+    monkeypatch.setenv("RT_GPU_TREE_STACK", str(levels))
+    short = gpu.GpuScene(sh)
+    monkeypatch.delenv("RT_GPU_TREE_STACK")
+    monkeypatch.delenv("RT_GPU_FINISH_BELOW")
+    W, H, spp, seed = 160, 96, 5, 77
+    want = oracle_counter(sh, W, H, (0, 0, W, H), spp, seed)
+    counters = []
+    for g in (gs, short):
+        img, got = host.new_image(W, H)
+        g.reset_stats()
+        g.render_region(img, (0, 0, W, H), spp, seed, gpu.Options(flags=gpu.FLAG_DETAILED_STATS))
+        assert L.same_bits(got, want).all()
+        st = g.stats()
+        counters.append({k: st[k] for k in ("rays", "interior_pops", "leaf_pops", "tri_tests", "tri_hits", "tree_entries")})
+        hist = g.stack_histogram()
+        assert sum(hist) > 0 and sum(hist[9:]) > 0, hist       # some walks need more than 8 entries
+        assert sum(hist[levels + 1:]) > sum(hist) // 20 or g is gs, hist
+    assert counters[0] == counters[1], counters
+    rng = np.random.default_rng(5)
+    n = 4096
+    o = np.tile(np.array([0.0, 10.0, 85.0], np.float32), (n, 1))
+    d = rng.standard_normal((n, 3)).astype(np.float32) * np.array([0.5, 0.3, 0.0], np.float32) + np.array([0, -0.1, -1], np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d.astype(np.float32)], axis=1).astype(np.float32)
+    assert bytes(short.find_ray_hit(rays, FLT_MAX)) == bytes(short.find_ray_hit(rays, FLT_MAX, serial=True))
+    assert bytes(short.find_ray_hit(rays, FLT_MAX)) == bytes(gs.find_ray_hit(rays, FLT_MAX))
+    short.close()
+    gs.close()
+
+
 def test_lists_start_small_and_grow_when_a_batch_needs_a_second_pass(monkeypatch):
     """A handle starts with lists of paths in transit of 40 % of the worst case (every path of the batch
     parked at once).  The dog room parks a quarter of its paths: one pass, the lists stay.  Dogs and cat parks
