@@ -277,13 +277,13 @@ def main():
                     help="frames whose shares one render call produces (0 = 1 on one GPU, min(N, 8) when N GPUs share a frame)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="render calls under way at once, each ordered on its own stream and using its own work-memory "
-                         "lane of the one scene handle (0 = 3)")
+                         "lane of the one scene handle (0 = 4, the hardware queues of a process)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else 3
+    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else 4
     os.environ.setdefault("RT_GPU_STREAMS", str(max(3, in_flight)))      # lanes of the scene handle (read when it is made)
     import torch
     from raytracing_amd import gpu, multi_gpu, scenes

@@ -1405,6 +1405,7 @@ struct rt_gpu_scene {
     hipStream_t host_stream = nullptr;                        /* rt_gpu_render_region (host image) orders its render here */
     Knobs knobs;
     uint32_t shade_blocks = 0, resume_blocks = 0, tree_blocks = 0, finish_blocks = 0;   /* persistent grid sizes */
+    uint32_t shade_blocks_shared = 0;                         /* the launch that starts paths while other lanes of the handle are busy */
     uint32_t tree_levels = 0;                                 /* stack entries per ray in the tree kernel's LDS (the rest in a lane's d_spill) */
     uint64_t spill_bytes = 0;                                 /* size of a lane's d_spill */
     uint64_t *d_depth_hist = nullptr;                         /* RT_DEPTH_BINS counters: rays by deepest stack (launches with detailed counters) */
@@ -1633,6 +1634,14 @@ int rt_gpu_scene_create(const rt_scene *scene, rt_gpu_scene **out)
             s->resume_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_resume);
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
             s->shade_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_shade);
+            /* With four frames in flight (calls on three other lanes of the handle still running) the launch that starts the
+             * paths leaves a quarter of every CU to the other frames' tree and resumed-path launches: it is bound by the
+             * vector unit and loses little with 3 of 4 workgroups, they wait for memory half of the time and fill the
+             * gap (measured with four calls in flight: 21.9 -> 21.4 ms per frame; with three in flight or alone the full
+             * grid is faster: 22.1 against 22.5 ms) */
+            int per_cu_shared = per_cu_shade > 1 ? per_cu_shade - 1 : per_cu_shade;
+            if (const char *e = getenv("RT_GPU_FRESH_BLOCKS_PER_CU_SHARED")) { int v = atoi(e); if (v >= 1 && v <= per_cu_shade) per_cu_shared = v; }
+            s->shade_blocks_shared = (uint32_t)(prop.multiProcessorCount * per_cu_shared);
             s->tree_blocks = (uint32_t)(prop.multiProcessorCount * per_cu_tree);
             /* one slice per thread of a tree launch for the stack entries beyond the LDS levels (at least one entry: the
              * pointer is never null) */
@@ -1884,6 +1893,12 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
     if (hipMemGetInfo(&free_bytes, &device_bytes) != hipSuccess) { (void)hipGetLastError(); free_bytes = ~(size_t)0; }
     uint64_t held = 0;
     for (uint32_t i = 0; i < K.lanes; i++) held += s->lanes[i].sample_bytes + 2 * s->lanes[i].parked_records * record_bytes;
+    /* are calls of this handle under way on at least three other lanes (four frames in flight)?  With fewer the full grid is faster */
+    uint32_t busy_lanes = 0;
+    for (uint32_t i = 0; i < K.lanes; i++)
+        if (i != first_lane % K.lanes && s->lanes[i].done && hipEventQuery(s->lanes[i].done) == hipErrorNotReady) busy_lanes++;
+    (void)hipGetLastError();
+    const bool others_busy = busy_lanes >= 3;
     uint32_t shade_grid = 0, resume_grid = 0, lanes_used = 0, lane_cap = K.lanes, passes = 1;
     uint64_t batches = 0, capacity = 0, out_limit = 0;
     (void)device_bytes;
@@ -1910,7 +1925,7 @@ int rt_gpu_render_region_device(rt_gpu_scene *s, float *device_pixels, uint32_t 
         /* no more workgroups than there are portions of fresh work for their waves (small regions); the
          * resumed-path launches get no more workgroups than the first launch */
         const uint64_t portions_max = units * ((batch_spp + RT_PORTION_SPP - 1) / RT_PORTION_SPP);
-        shade_grid = s->shade_blocks;
+        shade_grid = others_busy ? s->shade_blocks_shared : s->shade_blocks;
         if ((portions_max + 3) / 4 < shade_grid) shade_grid = (uint32_t)((portions_max + 3) / 4);
         resume_grid = s->resume_blocks < shade_grid ? s->resume_blocks : shade_grid;
         const uint64_t batch_paths = batch_spp * items_per_sample;
