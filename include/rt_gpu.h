@@ -163,7 +163,9 @@ int rt_gpu_render_region(rt_gpu_scene *scene, rt_image3f *image, rt_rect2u regio
  * batches that go round-robin over a few streams of the library's own
  * (RT_GPU_STREAMS, default 3; RT_GPU_BATCH_PATHS paths per batch, default 80 Mi, then
  * cut down to what RT_GPU_SCRATCH_MB, RT_GPU_PARKED_MB and the free device memory
- * allow: a 1024 x 1024 x 64 spp frame is one batch), so the latency-bound end of one
+ * allow: a 1024 x 1024 x 64 spp frame is one batch; the lists of paths in transit start at
+ * RT_GPU_PARKED_PERCENT, default 40, of the size that every path of a batch would need and grow to
+ * it only after a batch needed more than one pass: rt_gpu_stats.lists_full), so the latency-bound end of one
  * batch overlaps the start of the next; the picture does not depend on the batching.  Work that consumes the pixels goes
  * on `hip_stream` (or synchronises with it).  The buffer belongs to the caller
  * (e.g. a tensor that a collective will gather). */
