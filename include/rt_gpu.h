@@ -261,7 +261,7 @@ int rt_gpu_reset_stats(rt_gpu_scene *scene);
  * closest-hit probes) since the last reset: out[k] = rays parked for a tree whose stack never held more than k entries
  * (k = 31: 31 or more).  The reference sizes its stack for the tree's depth + 1 (src/main.c:393-395); the walk only
  * stacks the far one of two entered children, so the occupied depth is far smaller, and the tree kernel keeps
- * RT_GPU_TREE_STACK entries per ray (default 8) in LDS and deeper ones in device memory. */
+ * RT_GPU_TREE_STACK entries per ray (default 6) in LDS and deeper ones in device memory. */
 int rt_gpu_get_stack_histogram(rt_gpu_scene *scene, uint64_t out[32]);
 
 /* Self-test hook: evaluates the device's sin/cos/log/divide/sqrt building

@@ -530,11 +530,18 @@ struct TreeParams {
 
 #define RT_DEPTH_BINS 32u
 #ifndef RT_TREE_WAVES
-#define RT_TREE_WAVES 6               /* waves per SIMD the tree kernel is compiled for (0: compiler's choice): 80 registers; with its
-                                       * short LDS stack the workgroup needs 13 KB of LDS, so registers are what limits it */
+#define RT_TREE_WAVES 7               /* waves per SIMD the tree kernel is compiled for (0: compiler's choice): 72 registers.  The kernel waits for
+                                       * its dependent fetches, so resident waves are what it runs on: with the visited node's boxes staged in LDS
+                                       * instead of twelve registers (RT_TREE_STAGE_BOXES) seven fit without spilling inside the loop (8 would
+                                       * spill a dozen registers per lane: measured a quarter slower) */
+#endif
+#ifndef RT_TREE_LATE_FETCH
+#define RT_TREE_LATE_FETCH 0          /* experiment: no record a step ahead at all (16 registers less: 7 waves too); as fast as 6 waves with the
+                                       * record in registers, slower than 7 waves with the boxes staged */
 #endif
 #ifndef RT_TREE_STACK_LDS
-#define RT_TREE_STACK_LDS 8u          /* stack entries per ray the tree kernel keeps in LDS (deeper ones go to device memory);
+#define RT_TREE_STACK_LDS 6u          /* stack entries per ray the tree kernel keeps in LDS (deeper ones go to device memory): with the staged
+                                       * boxes (12 KB) and the leaf areas (4.5 KB) six levels (6 KB) let seven workgroups share a CU's LDS;
                                        * RT_GPU_TREE_STACK overrides it per scene handle */
 #endif
 #ifndef RT_TREE_LEAF_MIN
@@ -550,7 +557,12 @@ struct TreeParams {
 #define RT_LEAF_REDO 0                /* the ray that accepted a triangle computes its barycentrics again (0: the pair that won leaves them in LDS) */
 #endif
 #define RT_LEAF_WORDS_PER_WAVE (128u + (RT_LEAF_REDO ? 0u : 128u) + (RT_LEAF_MARKS ? 32u : 0u))   /* LDS words per wave for the leaf passes: 64 keys (2 words), 1024 mark bits, 64 x (beta, gamma) */
-#define RT_TREE_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * RT_LEAF_WORDS_PER_WAVE * 4u + (size_t)RT_TREE_TOP * 64u)   /* bytes per workgroup for the leaf passes and the tree tops */
+#ifndef RT_TREE_STAGE_BOXES
+#define RT_TREE_STAGE_BOXES 1         /* 1: the boxes of the node a lane visits next (48 of the record's 64 bytes) wait in LDS, fetched there a step
+                                       * ahead without passing through registers (global_load_lds); the two entries come through registers */
+#endif
+#define RT_TREE_STAGE_LDS (RT_TREE_STAGE_BOXES ? (size_t)RT_BLOCK * 48u : (size_t)0)
+#define RT_TREE_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * RT_LEAF_WORDS_PER_WAVE * 4u + (size_t)RT_TREE_TOP * 64u + RT_TREE_STAGE_LDS)   /* bytes per workgroup for the leaf passes and the tree tops */
 #ifndef RT_FINISH_SHADE_WEIGHT
 #define RT_FINISH_SHADE_WEIGHT 8      /* finish kernel: weight (in 1/16ths) of a lane that wants a shade step in the vote for the kind of step to run (a shade step is long: it should run fuller; measured 2 ... 16) */
 #endif
@@ -767,7 +779,15 @@ rt_tree_kernel(const TreeParams P)
     uint32_t in_cur = 0, in_end = 0;
     bool input_done = false;
     uint32_t cur = RT_ENTRY_NONE;                        /* entry the lane visits next; its record is in ra..rd */
+#if RT_TREE_LATE_FETCH
+    const rt::u32x4 *node_at = nullptr;                  /* experiment: the record is fetched when the node step runs, not a step ahead (16 registers less) */
+#elif RT_TREE_STAGE_BOXES
+    rt::u32x4 rd = 0;
+    /* per wave 3 quads x 64 lanes x 16 bytes, behind the leaf areas (and the tree tops): quad q of lane l at word (q * 64 + l) * 4 */
+    uint32_t *node_stage = lds + (size_t)RT_BLOCK * P.stack_levels + (RT_BLOCK / 64) * RT_LEAF_WORDS_PER_WAVE + (size_t)RT_TREE_TOP * 16u + wave * (3u * 64u * 4u);
+#else
     rt::u32x4 ra = 0, rb = 0, rc = 0, rd = 0;
+#endif
     bool stepped = false;                                /* the lane needs its next record */
     bool scan_wait = false;                              /* the lane's instance is done (or its ray is new): it waits to test the next instance's root box */
     int depth_max = 0;                                   /* counting builds: deepest stack of the lane's ray so far */
@@ -855,8 +875,17 @@ rt_tree_kernel(const TreeParams P)
         }
         RT_TICK(1)
         if (run_node) {
+#if RT_TREE_STAGE_BOXES
+            __builtin_amdgcn_s_waitcnt(0x0F70);          /* vmcnt(0): the boxes requested at the end of the previous iteration are in LDS */
+#endif
             if (STATS) { if (lane == 0) cn.pop_steps++; if (want_node) cn.pop_lanes++; }
             if (want_node) {
+#if RT_TREE_LATE_FETCH
+                const rt::u32x4 ra = node_at[0], rb = node_at[1], rc = node_at[2], rd = node_at[3];
+#elif RT_TREE_STAGE_BOXES
+                const rt::u32x4 *staged = reinterpret_cast<const rt::u32x4 *>(node_stage) + lane;
+                const rt::u32x4 ra = staged[0], rb = staged[64], rc = staged[128];
+#endif
                 rt::walk_node<STATS>(ra, rb, rc, rd, h, tv, stk, cur, cn); stepped = true;
                 if (STATS && tv.top + 1 > depth_max) depth_max = tv.top + 1;
             }
@@ -896,7 +925,19 @@ rt_tree_kernel(const TreeParams P)
                     ra = t[0]; rb = t[1]; rc = t[2]; rd = t[3];
                 } else
 #endif
+#if RT_TREE_LATE_FETCH
+                node_at = q;
+#elif RT_TREE_STAGE_BOXES
+                {
+                    const uint32_t *g = reinterpret_cast<const uint32_t *>(q);
+                    __builtin_amdgcn_global_load_lds(g, node_stage, 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(g + 4, node_stage + 256, 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(g + 8, node_stage + 512, 16, 0, 0);
+                    rd = q[3];
+                }
+#else
                 { ra = q[0]; rb = q[1]; rc = q[2]; rd = q[3]; }
+#endif
             }
             else if (next == rt::NEXT_DONE) finish();
         }

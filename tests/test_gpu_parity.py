@@ -854,10 +854,10 @@ def test_lists_smaller_than_a_batch_start_its_paths_in_passes(gpu_scenes, monkey
 
 @pytest.mark.parametrize("levels", [1, 3])
 def test_short_traversal_stack_spills_in_order(gpu_scenes, monkeypatch, levels):
-    """The tree kernel keeps a few stack entries per ray in LDS (8 by default) and deeper ones in device memory
+    """The tree kernel keeps a few stack entries per ray in LDS (6 by default) and deeper ones in device memory
     (src/main.c:393-395 sizes the stack for the whole depth of the tree).  With only 1 or 3 entries in LDS
     most walks use the spilled part: same pixels as the oracle, same probes as the one-by-one walk, the same
-    traversal counters as the default handle; and the histogram of deepest stacks shows that the default 8
+    traversal counters as the default handle; and the histogram of deepest stacks shows that the default
     entries are exceeded by a few walks of an ordinary render too (so that path runs in every frame)."""
     sh, _ = gpu_scenes("dogs_and_cat")
     monkeypatch.setenv("RT_GPU_FINISH_BELOW", "0")           # rounds of tree launches to the last path (a small frame would otherwise go to the finishing launch at once)
@@ -877,7 +877,7 @@ def test_short_traversal_stack_spills_in_order(gpu_scenes, monkeypatch, levels):
         st = g.stats()
         counters.append({k: st[k] for k in ("rays", "interior_pops", "leaf_pops", "tri_tests", "tri_hits", "tree_entries")})
         hist = g.stack_histogram()
-        assert sum(hist) > 0 and sum(hist[9:]) > 0, hist       # some walks need more than 8 entries
+        assert sum(hist) > 0 and sum(hist[9:]) > 0, hist       # some walks need more than 8 entries (the default keeps 6 in LDS)
         assert sum(hist[levels + 1:]) > sum(hist) // 20 or g is gs, hist
     assert counters[0] == counters[1], counters
     rng = np.random.default_rng(5)
