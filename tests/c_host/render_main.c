@@ -1,6 +1,6 @@
 /*
  * render_main.c -- a host program in plain C that renders with librt_gpu.so, the way the
- * reference's main() would after the change INTEGRATION.md describes: the scene is filled in by hand
+ * reference's main() would once it binds the library: the scene is filled in by hand
  * as C records (reference: src/main.c:885-1054), the block that starts the tile threads and calls
  * raytrace_region (src/main.c:1056-1088) is replaced by calls into the C ABI of include/rt_gpu.h.
  *
