@@ -294,6 +294,52 @@ def test_find_ray_hit_rays_inside_a_triangle_plane(gpu_scenes):
     gs.close()
 
 
+@pytest.mark.parametrize("log2_scale", [-30, 0, 45, 90])
+def test_find_ray_hit_at_extreme_scales(log2_scale):
+    """A triangle soup with a real tree, scaled by 2^-30 ... 2^90, and rays scaled with it: beyond 2^40 (and for
+    direction components below 2^-40) the shared-reciprocal box test and the certified approximate root test do not
+    apply and the kernels must fall back to the plain divisions; at 2^90 squared lengths overflow to infinity.
+    Every word of Ray_Result against the oracle, both device implementations (src/main.c:372-483)."""
+    s = np.float32(2.0 ** log2_scale)
+    rng = np.random.default_rng(11)
+    n_tri = 400
+    centre = rng.uniform(-1.0, 1.0, (n_tri, 1, 3))
+    corners = (centre + rng.uniform(-0.15, 0.15, (n_tri, 3, 3))).reshape(-1, 3)
+    p = np.vstack([np.zeros((1, 3)), corners]).astype(np.float32) * s
+    ids = np.array([[[3 * t + k + 1, 0, 1] for k in range(3)] for t in range(n_tri)], np.uint32).reshape(-1, 3)
+    mesh = host.mesh_from_obj_arrays(p, np.zeros((1, 2), np.float32), np.array([[0, 0, 0], [0, 0, 1]], np.float32),
+                                     ids, np.full(n_tri, 3, np.uint32))
+    assert mesh.tree_depth > 3
+    sh = scenes.SceneHandle("soup", scenes.room_camera(), scenes.room_materials(), [], [], [],
+                            [scenes.instance(mesh, (0.0, 0.0, 0.0), 0), scenes.instance(mesh, (float(2.5 * s), 0.0, 0.0), 0)],
+                            keep=[mesh])
+    gs = gpu.GpuScene(sh)
+    n = 3000
+    o = rng.standard_normal((n, 3))
+    o = (4.0 * o / np.linalg.norm(o, axis=1, keepdims=True)).astype(np.float32)
+    target = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32)
+    target[::3, 0] += 2.5                                    # a third of the rays aim at the second instance
+    d = (target - o).astype(np.float64)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[::7, 1] = np.float32(2.0 ** -50) * np.sign(d[::7, 1] + 0.5)   # tiny but not zero: outside the shared-reciprocal range
+    d[::11, 2] = np.float32(1e-41)                           # denormal direction components
+    rays = np.hstack([o * s, d]).astype(np.float32)
+    for maxd in (FLT_MAX, float(4.5 * s)):
+        want = (T.RayResult * n)()
+        for i in range(n):
+            ray = T.Ray(T.Vec3f(*rays[i, :3].tolist()), T.Vec3f(*rays[i, 3:].tolist()))
+            L.oracle().orc_find_ray_hit(sh.ptr, C.byref(ray), maxd, C.byref(want[i]), None)
+        want_f = _result_fields(want)
+        for serial in (False, True):
+            got_f = _result_fields(gs.find_ray_hit(rays, maxd, serial=serial))
+            for f, w in want_f.items():
+                same = (L.same_bits(got_f[f], w) | (np.isnan(got_f[f]) & np.isnan(w))) if w.dtype == np.float32 else (got_f[f] == w)
+                assert same.all(), (log2_scale, serial, maxd, f, np.nonzero(~same.reshape(n, -1).all(axis=1))[0][:5])
+        if maxd == FLT_MAX and log2_scale >= 0:
+            assert (want_f["object_type"][want_f["hit"] != 0] == 3).sum() > 300    # the rays do hit triangles
+    gs.close()
+
+
 # ---------------------------------------------------------------- the render loop, counter generator
 
 @pytest.mark.parametrize("name", SCENES)
