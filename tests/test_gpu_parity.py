@@ -758,6 +758,31 @@ def test_degenerate_scenes():
         g.close()
 
 
+@pytest.mark.parametrize("log2_scale", [-12, 24, 50])
+def test_render_region_at_extreme_scales(log2_scale):
+    """The sphere room (diffuse, mirror and glass spheres, five planes, two lights) with every length scaled by
+    2^-12, 2^24 and 2^50: squared lengths leave the range in which normalisations share one reciprocal and square
+    roots skip their scaling steps (at 2^50 they reach 2^115), so the paths take the plain forms; at 2^-12 most
+    hits fall under the host's 1e-3 threshold.  Bit-equal to the oracle whatever the picture shows."""
+    s = float(2.0 ** log2_scale)
+    cam = scenes.room_camera()
+    cam.position = T.Vec3f(0.0, 10.0 * s, 85.0 * s)
+    spheres = [T.Sphere(T.Vec3f(c.center.x * s, c.center.y * s, c.center.z * s), c.radius * s, c.material_id) for c in scenes.room_spheres()]
+    planes = [T.Plane(T.Vec3f(p.normal.x, p.normal.y, p.normal.z), p.d * s, p.material_id) for p in scenes.room_planes()]
+    lights = [T.Light(T.Vec3f(l.center.x * s, l.center.y * s, l.center.z * s), l.radius * s, T.Vec3f(l.color.x, l.color.y, l.color.z),
+                      l.albedo * min(s * s, 1e30)) for l in scenes.room_lights()]
+    sh = scenes.SceneHandle("scaled_room", cam, scenes.room_materials(), spheres, planes, lights, [])
+    g = gpu.GpuScene(sh)
+    img, got = host.new_image(40, 32)
+    g.render_region(img, (0, 0, 40, 32), 6, 9)
+    want = oracle_counter(sh, 40, 32, (0, 0, 40, 32), 6, 9)
+    same = L.same_bits(got, want) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), (log2_scale, int((~same).sum()))
+    if log2_scale > 0:
+        assert np.isfinite(want).all() and (want > 0).any()
+    g.close()
+
+
 def test_errors_are_reported_not_crashed(gpu_scenes):
     sh, gs = gpu_scenes("sphere_room")
     img, _ = host.new_image(16, 16)
