@@ -783,6 +783,25 @@ def test_render_region_at_extreme_scales(log2_scale):
     g.close()
 
 
+@pytest.mark.parametrize("n_lights", [0, 1, 3, 5])
+def test_light_counts(n_lights):
+    """The number of lights decides how many shadow rays a vertex sends and which kind of step follows which
+    (src/main.c:540-640): none, one, three and five lights in the sphere room with the dog in it."""
+    rng = np.random.default_rng(n_lights)
+    lights = [T.Light(T.Vec3f(float(rng.uniform(-40, 40)), float(rng.uniform(15, 60)), float(rng.uniform(0, 75))), float(rng.uniform(1, 4)),
+                      T.Vec3f(*rng.uniform(0.2, 1.0, 3).tolist()), float(rng.uniform(1e4, 1e5))) for _ in range(n_lights)]
+    mesh, texture = scenes.load_dog_mesh(), scenes.load_dog_texture()
+    sh = scenes.SceneHandle("lights", scenes.room_camera(), scenes.room_materials(texture), scenes.room_spheres(), scenes.room_planes(),
+                            lights, [scenes.instance(mesh, (12.0, -10.0, 30.0), 8)], keep=[mesh, texture])
+    g = gpu.GpuScene(sh)
+    img, got = host.new_image(48, 40)
+    g.render_region(img, (0, 0, 48, 40), 5, 3)
+    want = oracle_counter(sh, 48, 40, (0, 0, 48, 40), 5, 3)
+    assert L.same_bits(got, want).all(), (n_lights, int((~L.same_bits(got, want)).sum()))
+    assert (want > 0).any() == (n_lights > 0)
+    g.close()
+
+
 def test_errors_are_reported_not_crashed(gpu_scenes):
     sh, gs = gpu_scenes("sphere_room")
     img, _ = host.new_image(16, 16)
