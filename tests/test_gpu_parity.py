@@ -802,6 +802,34 @@ def test_light_counts(n_lights):
     g.close()
 
 
+def test_many_rotated_instances():
+    """Seven instances of the two meshes, each with its own rotation (rows of a general rotation matrix, one of them
+    mirrored) and material (textured, mirror, glass): the ray is taken into mesh space per instance
+    (src/math.c:299-311) and a ray that leaves one instance's tree goes on to the next one's root box."""
+    rng = np.random.default_rng(5)
+    dog, cat = scenes.load_dog_mesh(), scenes.load_cat_mesh()
+    texture = scenes.load_dog_texture()
+    insts = []
+    for k in range(7):
+        a, b = rng.uniform(0, 2 * np.pi), rng.uniform(-0.4, 0.4)
+        ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        rot = (rx @ ry).astype(np.float32)
+        if k == 3:
+            rot[0] = -rot[0]
+        sm = scenes.instance(cat if k % 3 == 2 else dog, (float(28 * np.cos(k)), -10.0 + 3.0 * (k % 2), float(20 + 22 * np.sin(k))), (8, 5, 7)[k % 3])
+        sm.transform.rotX, sm.transform.rotY, sm.transform.rotZ = (T.Vec3f(*rot[i].tolist()) for i in range(3))
+        insts.append(sm)
+    sh = scenes.SceneHandle("ring", scenes.room_camera(), scenes.room_materials(texture), [], scenes.room_planes(),
+                            scenes.room_lights(), insts, keep=[dog, cat, texture])
+    g = gpu.GpuScene(sh)
+    img, got = host.new_image(64, 48)
+    g.render_region(img, (0, 0, 64, 48), 4, 21)
+    want = oracle_counter(sh, 64, 48, (0, 0, 64, 48), 4, 21)
+    assert L.same_bits(got, want).all(), int((~L.same_bits(got, want)).sum())
+    g.close()
+
+
 def test_errors_are_reported_not_crashed(gpu_scenes):
     sh, gs = gpu_scenes("sphere_room")
     img, _ = host.new_image(16, 16)
