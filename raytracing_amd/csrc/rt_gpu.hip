@@ -561,6 +561,9 @@ struct TreeParams {
 #define RT_TREE_STAGE_BOXES 1         /* 1: the boxes of the node a lane visits next (48 of the record's 64 bytes) wait in LDS, fetched there a step
                                        * ahead without passing through registers (global_load_lds); the two entries come through registers */
 #endif
+#if RT_TREE_TOP && RT_TREE_LATE_FETCH
+#error "RT_TREE_TOP is not implemented for RT_TREE_LATE_FETCH"
+#endif
 #define RT_TREE_STAGE_LDS (RT_TREE_STAGE_BOXES ? (size_t)RT_BLOCK * 48u : (size_t)0)
 #define RT_TREE_EXTRA_LDS ((size_t)(RT_BLOCK / 64) * RT_LEAF_WORDS_PER_WAVE * 4u + (size_t)RT_TREE_TOP * 64u + RT_TREE_STAGE_LDS)   /* bytes per workgroup for the leaf passes and the tree tops */
 #ifndef RT_FINISH_SHADE_WEIGHT
@@ -884,7 +887,14 @@ rt_tree_kernel(const TreeParams P)
                 const rt::u32x4 ra = node_at[0], rb = node_at[1], rc = node_at[2], rd = node_at[3];
 #elif RT_TREE_STAGE_BOXES
                 const rt::u32x4 *staged = reinterpret_cast<const rt::u32x4 *>(node_stage) + lane;
-                const rt::u32x4 ra = staged[0], rb = staged[64], rc = staged[128];
+                rt::u32x4 ra, rb, rc;
+#if RT_TREE_TOP
+                if (tv.mesh < top_meshes && cur < top_each) {        /* a record of the tree top: from the workgroup's copy */
+                    const rt::u32x4 *t = reinterpret_cast<const rt::u32x4 *>(tops + ((size_t)tv.mesh * top_each + cur) * 16u);
+                    ra = t[0]; rb = t[1]; rc = t[2]; rd = t[3];
+                } else
+#endif
+                { ra = staged[0]; rb = staged[64]; rc = staged[128]; }
 #endif
                 rt::walk_node<STATS>(ra, rb, rc, rd, h, tv, stk, cur, cn); stepped = true;
                 if (STATS && tv.top + 1 > depth_max) depth_max = tv.top + 1;
@@ -919,7 +929,10 @@ rt_tree_kernel(const TreeParams P)
             const int next = rt::walk_advance<STATS>(P.S, o, d, h, tv, stk, cur, q, cn, may_scan);
             if (next == rt::NEXT_SCAN) scan_wait = true;
             if (next == rt::NEXT_NODE) {
-#if RT_TREE_TOP
+#if RT_TREE_TOP && RT_TREE_STAGE_BOXES && !RT_TREE_LATE_FETCH
+                if (tv.mesh < top_meshes && cur < top_each) { }      /* nothing to request: the node step reads the workgroup's copy */
+                else
+#elif RT_TREE_TOP
                 if (tv.mesh < top_meshes && cur < top_each) {
                     const rt::u32x4 *t = reinterpret_cast<const rt::u32x4 *>(tops + ((size_t)tv.mesh * top_each + cur) * 16u);
                     ra = t[0]; rb = t[1]; rc = t[2]; rd = t[3];
