@@ -15,7 +15,8 @@ extern "C" {
 /* Replaces split_mesh_node (reference: src/main.c:92-175) called on the root as
  * load_mesh does (src/main.c:256-258): rebuilds mesh->root and mesh->tree_depth
  * and permutes mesh->faces in place, node for node and swap for swap as the
- * reference.  Returns 0, or <0 on bad input / out of memory. */
+ * reference.  mesh->root.childs must be NULL or a tree made by one of these builders (it is freed).
+ * Returns 0, or <0 on bad input / out of memory. */
 int rt_host_mesh_build_tree(rt_mesh *mesh);
 
 /* A second builder with no counterpart in the reference: per node the axis and plane of least

@@ -119,6 +119,7 @@ int rt_host_mesh_build_tree(rt_mesh *mesh)
     pool.used = 0;
     pool.nodes = calloc(pool.cap, sizeof(rt_mesh_node));
     if (!pool.nodes) return -2;
+    free(mesh->root.childs);                         /* a tree built before (the pool starts at the root's first child) */
     mesh->tree_depth = 0;
     memset(&mesh->root, 0, sizeof(mesh->root));
     mesh->root.first_triangle_id = 0;
