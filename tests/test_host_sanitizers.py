@@ -17,6 +17,11 @@ SAN = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undef
 
 def run(cmd, **kw):
     done = subprocess.run(cmd, capture_output=True, text=True, timeout=600, **kw)
+    if done.returncode != 0 and "LeakSanitizer has encountered a fatal error" in done.stderr and "env" in kw:
+        # the leak checker cannot stop the process's threads under some supervisors (it needs ptrace): the other checks still run
+        env = dict(kw["env"])
+        env["ASAN_OPTIONS"] = env["ASAN_OPTIONS"].replace("detect_leaks=1", "detect_leaks=0")
+        done = subprocess.run(cmd, capture_output=True, text=True, timeout=600, **{**kw, "env": env})
     assert done.returncode == 0, (cmd[0], done.stdout[-2000:], done.stderr[-4000:])
     return done.stdout
 
